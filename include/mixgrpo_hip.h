@@ -1,0 +1,127 @@
+/*
+ * libmixgrpo_hip.so -- C ABI of the MI355X-native MixGRPO rollout-and-update hot path.
+ *
+ * The reference (zqqqqz2000/MixGRPO) is pure Python and has no FFI layer; its boundary for this path is
+ * the function surface of fastvideo/utils/sampling_utils.py and fastvideo/train_grpo_flux.py, which calls
+ * PyTorch eager ops.  Every entry point below replaces the eager-op sequence of one reference function
+ * (cited per function, paths relative to the reference root).  The Python mirror in mixgrpo_amd/ binds
+ * them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: plain pointers to DEVICE memory unless a parameter says "host"; sizes as int/long; scalars
+ * by value; `stream` is a hipStream_t passed as void*.  No allocation, no host sync, no global mutable
+ * state except the thread-local last-error string.  Returns 0 (MGX_OK) or a negative error code; the
+ * message is available from mgx_last_error().  bf16 tensors are passed as uint16_t*.
+ */
+#ifndef MIXGRPO_HIP_H
+#define MIXGRPO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int mgx_version(void);
+const char* mgx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ solver
+ * Host-computed per-step scalars.  They are produced on the host (mixgrpo_amd/sampling_utils.py) in the
+ * reference's own fp32 operation order, including which scalars PyTorch rounds to bf16 before multiplying
+ * a bf16 tensor (oracle/solver.py header), so the kernels only apply them.
+ */
+typedef struct {
+  float sigma_x0; /* x0   = x - bf16(v * sigma_x0)                       sampling_utils.py:175 */
+  float c_x;      /* mean = x * c_x + bf16(bf16(v * c_v) * dt_mean)      sampling_utils.py:186 */
+  float c_v;
+  float dt_mean;
+  float sd_noise; /* prev = mean + bf16(noise * sd_noise)                sampling_utils.py:195 */
+  float dt_det;   /* deterministic: prev = x + bf16(v * dt_det)          sampling_utils.py:199 */
+  float den;      /* 2*sd^2                                              sampling_utils.py:202 */
+  float log_sd;   /* log(sd)                                             sampling_utils.py:203 */
+  float log_c;    /* log(sqrt(2*pi))                                     sampling_utils.py:204 */
+} mgx_flow_coeffs;
+
+/* Elements of `ws` (double) the log-prob reduction needs for a [B, n] problem. */
+long mgx_logp_workspace_elems(int B, long n);
+
+/* flow_grpo_step forward (sampling_utils.py:157-210).  x fp32 [B,n]; v bf16 [B,n].
+ * Rollout: noise bf16 [B,n] given, prev_in NULL -> writes prev_out.  Replay (training, :149-157 of
+ * train_grpo_flux.py): prev_in fp32 given, noise NULL, prev_out may be NULL.  deterministic!=0 applies the
+ * ODE override (:198-199) after the draw.  x0_out / mean_out are optional (NULL to skip).
+ * logp fp32 [B] = mean over n of the Gaussian log-density (:201-208). */
+int mgx_flow_step_fwd(const float* x, const uint16_t* v, const uint16_t* noise, const float* prev_in,
+                      float* prev_out, float* x0_out, float* mean_out, float* logp, double* ws, int B, long n,
+                      const mgx_flow_coeffs* k /*host*/, int deterministic, void* stream);
+
+/* d logp / d v for the replay path (autograd of sampling_utils.py:186,201-208): dv bf16 [B,n],
+ * g_logp fp32 [B] is dLoss/dlogp. */
+int mgx_flow_step_bwd(const float* x, const uint16_t* v, const float* prev, const float* g_logp, uint16_t* dv,
+                      int B, long n, const mgx_flow_coeffs* k /*host*/, void* stream);
+
+typedef struct {
+  float ds_r;     /* mean0 = x + bf16(v * ds_r)        sampling_utils.py:224 (scalar rounded to bf16) */
+  float s_r;      /* x0    = x - bf16(v * s_r)         sampling_utils.py:226 */
+  float ds;       /* unrounded sigma_next - sigma (score-correction term :234) */
+  float ds_b;     /* scalar autograd uses for d(ds*v)/dv (unrounded on CPU semantics) */
+  float s_b;      /* scalar autograd uses for d(s*v)/dv */
+  float one_m_s;  /* 1 - sigma                         sampling_utils.py:232 */
+  float s_sq;     /* sigma^2 */
+  float half_eta2;/* -0.5*eta^2 as fp32                sampling_utils.py:233 */
+  float sd;       /* eta*sqrt(sigma - sigma_next) as fp32 :229 */
+  float den;      /* 2*sd^2 as fp32                    :245 */
+} mgx_dance_coeffs;
+
+/* dance_grpo_step forward with grpo=True (sampling_utils.py:212-253).  noise fp32 [B,n] (SDE rollout) or
+ * NULL; prev_in fp32 (replay) or NULL; sde!=0 adds the score correction (:231-234). */
+int mgx_dance_step_fwd(const float* x, const uint16_t* v, const float* noise, const float* prev_in,
+                       float* prev_out, float* x0_out, float* logp, double* ws, int B, long n,
+                       const mgx_dance_coeffs* k /*host*/, int sde, void* stream);
+int mgx_dance_step_bwd(const float* x, const uint16_t* v, const float* prev, const float* g_logp, uint16_t* dv,
+                       int B, long n, const mgx_dance_coeffs* k /*host*/, int sde, void* stream);
+
+typedef struct {
+  int order;        /* 1..3: which multistep update (sampling_utils.py:327-357) */
+  int sde;          /* x = mean + sd_noise*noise instead of the ODE combination */
+  float sigma_x0;   /* x0 = sample - bf16(v*sigma_x0)            :387-396 */
+  float inv_r0;     /* D1_0 = inv_r0*(m0-m1)                     :490,608 */
+  float inv_r1;     /* D1_1 = inv_r1*(m1-m2)                     :608 */
+  float c_r;        /* D1 = D1_0 + c_r*(D1_0-D1_1)               :609 */
+  float inv_r01;    /* D2 = inv_r01*(D1_0-D1_1)                  :610 */
+  float cm[4];      /* mean = cm0*sample + cm1*D0 + cm2*D1 + cm3*D2 (signed, summed left to right) */
+  float cx[4];      /* x    = cx0*sample + cx1*D0 + cx2*D1 + cx3*D2 */
+  float sd_noise;   /* std*dt_sqrt */
+  float den;        /* 2*(std*dt_sqrt)^2 */
+  float log_sd;
+  float log_c;
+} mgx_dpm_coeffs;
+
+/* dpm_step (sampling_utils.py:273-385) for DPM-Solver / DPM-Solver++ orders 1-3.  m1/m2 are the previous
+ * x0 predictions (fp32, NULL when order is lower); x0_out receives this step's x0 (the new m0). */
+int mgx_dpm_step_fwd(const float* sample, const uint16_t* v, const float* m1, const float* m2, const float* noise,
+                     float* x_out, float* x0_out, float* logp, double* ws, int B, long n,
+                     const mgx_dpm_coeffs* k /*host*/, void* stream);
+
+/* convert_model_output alone (sampling_utils.py:387-396; used at :116 to feed DPMState inside the window) */
+int mgx_x0_pred(const float* sample, const uint16_t* v, float* x0_out, long total, float sigma_x0, void* stream);
+
+/* pack_latents / unpack_latents (train_grpo_flux.py:94-115): [B,C,H,W] <-> [B,(H/2)(W/2),4C]; elem_size 2|4 */
+int mgx_pack_latents(const void* in, void* out, int B, int C, int H, int W, int elem_size, void* stream);
+int mgx_unpack_latents(const void* in, void* out, int B, int C, int H, int W, int elem_size, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ GRPO
+ * Group-relative advantage (train_grpo_flux.py:440-491): per group of G consecutive rewards,
+ * (r-mean)/(unbiased std+1e-8), statistics over the upper (1-trimmed_ratio) part when trimmed_ratio>0;
+ * out[i] (+)= weight * advantage (accumulate!=0 implements the multi-reward sum of :465-467). */
+int mgx_group_advantage(const float* rewards, float* out, int n, int G, float trimmed_ratio, float weight,
+                        int accumulate, void* stream);
+/* Global normalisation for use_group=False (:498): (r - mean(all))/(std(all)+1e-8); all = gathered rewards */
+int mgx_global_advantage(const float* rewards, const float* gathered, float* out, int n, int n_all, void* stream);
+
+/* PPO-clip GRPO loss per replayed transition (train_grpo_flux.py:560-583), batch of B independent
+ * (sample, step) pairs: loss/policy/kl/clip_frac per element and g_logp = dloss/dnew_logp. */
+int mgx_grpo_loss(const float* new_logp, const float* old_logp, const float* adv, int B, float clip_range,
+                  float adv_clip_max, float kl_coeff, float denom, float* loss, float* policy, float* kl,
+                  float* clip_frac, float* g_logp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,88 @@
+"""Builds mixgrpo_amd/csrc/*.hip into libmixgrpo_hip.so for gfx950 with hipcc (in-tree, no torch extension).
+
+`python -m mixgrpo_amd.build [--force]`.  hipcc cross-compiles without a GPU; the .so is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(CSRC, "libmixgrpo_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-variable", "-Wno-unused-result"]
+# files whose results must be bit-identical to separately-rounded eager fp32 ops: no FMA contraction
+PER_FILE = {"solver.hip": ["-ffp-contract=off"], "grpo.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path, flags):
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for p in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+            [os.path.join(HERE, "..", "include", "mixgrpo_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for src in _sources():
+        flags = COMMON + PER_FILE.get(src, [])
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        stamp = obj + ".sha"
+        dig = _digest(path, flags)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((src, [hipcc] + flags + ["-c", path, "-o", obj], stamp, dig))
+
+    def run(job):
+        src, cmd, stamp, dig = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        with open(stamp, "w") as f:
+            f.write(dig)
+        return src
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for s in ex.map(run, jobs):
+                if verbose:
+                    print(f"[mixgrpo_amd.build] compiled {s}")
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[mixgrpo_amd.build] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

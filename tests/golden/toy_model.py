@@ -33,3 +33,25 @@ class ToyTransformer(nn.Module):
 
     def clip_grad_norm_(self, max_norm):
         return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
+
+
+class ElementwiseToy(nn.Module):
+    """Velocity model made of separately-rounded fp32 elementwise ops only, so CPU and GPU agree bit for bit."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Parameter(torch.tensor(0.37))
+        self.config = {"toy": True}
+
+    def forward(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids,
+                pooled_projections, img_ids, joint_attention_kwargs=None, return_dict=False):
+        x = hidden_states.to(torch.float32)
+        tt = timestep.to(torch.float32).view(-1, 1, 1)
+        pos = (img_ids.to(torch.float32)[..., 1] * 0.125 + img_ids.to(torch.float32)[..., 2] * 0.0625).reshape(1, -1, 1)
+        h = x * self.a
+        h = h + tt
+        h = h - pos
+        return (h.to(torch.bfloat16),)
+
+    def clip_grad_norm_(self, max_norm):
+        return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
