@@ -167,12 +167,13 @@ def test_rollout_vs_oracle(case):
     ehs, pooled = R_["in/ehs"].repeat(2, 1, 1), R_["in/pooled"].repeat(2, 1)
     text_ids, ids = R_["in/text_ids"].repeat(2, 1), R_["in/img_ids"]
     g = torch.Generator().manual_seed(99)
-    flow = a.flow_grpo_sampling
-    noises = [torch.randn(z0.shape, generator=g).to(torch.bfloat16 if flow and "all" != a.dpm_apply_strategy or
-                                                     (flow and a.dpm_algorithm_type == "null") else torch.float32)
-              for _ in range(T)]
     if "dpmsolver" in a.dpm_algorithm_type and a.dpm_apply_strategy == "all":
-        noises = [n.float() for n in noises]
+        ndt = torch.float32       # dpm_step draws fp32 noise (reference :319-321)
+    elif a.flow_grpo_sampling:
+        ndt = torch.bfloat16      # flow_grpo_step draws in model_output.dtype (:189-194)
+    else:
+        ndt = torch.float32       # dance_grpo_step: randn_like(fp32 mean) (:238)
+    noises = [torch.randn(z0.shape, generator=g).to(ndt) for _ in range(T)]
     m_cpu, m_gpu = ElementwiseToy(), ElementwiseToy().cuda()
     with torch.no_grad():
         oz, olat, oall, olp = OR.run_sample_step(a, z0, range(T), sig, m_cpu, ehs, pooled, text_ids[:1], ids, True, det,
