@@ -16,6 +16,7 @@ import math
 from dataclasses import dataclass
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -414,10 +415,12 @@ def run_sample_step(args, z, progress_bar, sigma_schedule, transformer, encoder_
     n_run = 0
     for i in progress_bar:
         timestep_value = int(sig[i] * 1000)
-        timesteps = torch.full([B], timestep_value, device=dev, dtype=torch.long)
+        # int(sigma*1000)/1000 formed on the host as an IEEE fp32 division (reference :64-71 divides a long
+        # tensor by 1000 on the device, where eager mode multiplies by the reciprocal instead)
+        timestep = torch.full([B], float(np.float32(timestep_value) / np.float32(1000)), device=dev, dtype=_F32)
         transformer.eval()
         with torch.autocast("cuda", torch.bfloat16):
-            pred = transformer(hidden_states=z, encoder_hidden_states=encoder_hidden_states, timestep=timesteps / 1000,
+            pred = transformer(hidden_states=z, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
                                guidance=guidance, txt_ids=txt_ids, pooled_projections=pooled_prompt_embeds,
                                img_ids=image_ids, joint_attention_kwargs=None, return_dict=False)[0]
         zf = buf[i] if i > 0 else buf[0]

@@ -12,3 +12,29 @@ def load_golden(name):
     with open(os.path.join(GOLDEN, name + ".json")) as f:
         meta = json.load(f)
     return tensors, meta
+
+
+def host_matches_fixture_host():
+    """torch's CPU scalar math (sqrt/log of 0-dim tensors) is not bit-stable across hosts: the fixtures carry the
+    generating host's last bits.  True when this host reproduces them (then comparisons are bit-exact)."""
+    import torch
+    t, _ = load_golden("solver_steps")
+    sig = t["sigma/shift3.0_T25"]
+    s, dt = sig[2], sig[3] - sig[2]
+    std = torch.sqrt(s / (1 - s)) * 0.7
+    return (1 + std ** 2 / (2 * s) * dt).item() == 0.8668485283851624 and \
+        torch.log(std * torch.sqrt(-1 * dt)).item() == -0.6758469939231873
+
+
+def assert_same(a, b, exact=True, rtol=2e-6, atol=2e-6):
+    """Bit-exact comparison (NaNs equal), or a few-ulp tolerance when `exact` is False."""
+    import torch
+    a = a.detach().cpu()
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    if exact:
+        assert torch.equal(torch.nan_to_num(a, nan=777.0), torch.nan_to_num(b, nan=777.0)), (a - b).abs().max()
+    else:
+        fin = torch.isfinite(b)
+        assert torch.equal(a[~fin & ~torch.isnan(b)], b[~fin & ~torch.isnan(b)])
+        assert torch.allclose(a[fin].float(), b[fin].float(), rtol=rtol, atol=atol), (a[fin].float() - b[fin].float()).abs().max()

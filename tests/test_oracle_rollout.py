@@ -4,7 +4,7 @@ from argparse import Namespace
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import assert_same, host_matches_fixture_host, load_golden
 from oracle import rollout as R
 from oracle import solver as S
 from toy_model import ToyTransformer
@@ -12,9 +12,11 @@ from toy_model import ToyTransformer
 T_, M_ = load_golden("rollout")
 
 
+EXACT = host_matches_fixture_host()
+
+
 def eq(a, b):
-    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
-    assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (a - b).abs().max()
+    assert_same(a, b, exact=EXACT)
 
 
 @pytest.mark.parametrize("inject", [False, True])

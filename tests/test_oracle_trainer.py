@@ -6,11 +6,13 @@ from argparse import Namespace
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import assert_same, host_matches_fixture_host, load_golden
 from oracle import trainer as OT
 from toy_model import ToyTransformer
 
 T_, M_ = load_golden("trainer")
+EXACT = host_matches_fixture_host()
+TOL = 0.0 if EXACT else 1e-3
 
 
 class _Sched:
@@ -48,15 +50,15 @@ def close(a, b, tol=0.0):
 def test_train_one_step(case):
     res, model, _ = run_case(case)
     ret = case["ret"]
-    assert close(res[0], ret["total_loss"]), (res[0], ret["total_loss"])
-    assert close(res[1], ret["grad_norm"]), (res[1], ret["grad_norm"])
-    assert close(res[2], ret["policy_total_loss"])
-    assert close(res[3], ret["kl_total_loss"])
-    assert close(res[4], ret["total_clip_frac"])
+    assert close(res[0], ret["total_loss"], TOL), (res[0], ret["total_loss"])
+    assert close(res[1], ret["grad_norm"], TOL), (res[1], ret["grad_norm"])
+    assert close(res[2], ret["policy_total_loss"], TOL)
+    assert close(res[3], ret["kl_total_loss"], TOL)
+    assert close(res[4], ret["total_clip_frac"], TOL)
     assert res[5] == ret["reward_mean"]
     for n, p in model.named_parameters():
         exp = T_[f"{case['tag']}/param_after/{n}"]
-        assert torch.equal(torch.nan_to_num(p.detach(), nan=777.0), torch.nan_to_num(exp, nan=777.0)), n
+        assert_same(p.detach(), exp, exact=EXACT, rtol=1e-3, atol=1e-5)
 
 
 def test_known_answer_advantages():
