@@ -121,6 +121,36 @@ int mgx_grpo_loss(const float* new_logp, const float* old_logp, const float* adv
                   float adv_clip_max, float kl_coeff, float denom, float* loss, float* policy, float* kl,
                   float* clip_frac, float* g_logp, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ MMDiT
+ * The FLUX MMDiT is third-party code for the reference (diffusers 0.32.2 FluxTransformer2DModel, call sites
+ * fastvideo/utils/sampling_utils.py:68-82 and fastvideo/train_grpo_flux.py:134-144); each entry point below
+ * replaces the torch/cuBLAS/SDPA kernels that module launches under autocast(bf16).
+ *
+ * Row-batched matrices: row m lives at base + (m / rpb) * bstride + (m % rpb) * ld (elements).  A plain
+ * matrix has rpb >= M.  This lets the text rows and image rows of the joint [B, S, d] stream be operands
+ * without a concat/split copy.
+ */
+enum { MGX_EPI_BIAS = 0, MGX_EPI_BIAS_GELU = 1, MGX_EPI_BIAS_GATE_RES = 2, MGX_EPI_F32_ACC = 3, MGX_EPI_DGELU = 4 };
+
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); bf16 in, fp32 accumulate (MFMA), one rounding to bf16
+ * (nn.Linear under autocast).  Epilogues:
+ *   MGX_EPI_BIAS          C = bf16(acc + bias)
+ *   MGX_EPI_BIAS_GELU     C = bf16(gelu_tanh(bf16(acc + bias)));  aux (optional) receives the pre-activation
+ *   MGX_EPI_BIAS_GATE_RES C = bf16(C + bf16(gate[m/c_rpb, n] * bf16(acc + bias)));  aux (optional) <- pre-gate
+ *   MGX_EPI_F32_ACC       C(fp32) = beta * C + acc                  (weight gradients)
+ *   MGX_EPI_DGELU         C = bf16(bf16(acc) * gelu_tanh'(aux))     (input gradient through GELU)
+ * K % 64 == 0, N % 4 == 0; M, N tails are masked. */
+int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
+                  uint16_t* aux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                  long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream);
+
+/* out[N, ld_out] = in[M, N]^T (bf16; columns M..ld_out-1 are zero-filled) and, optionally, fp32 column sums
+ * colsum_out[n] = beta*colsum_out[n] + sum_m in[m, n] (bias gradients) via a deterministic two-stage reduction;
+ * colsum_partial needs mgx_transpose_partial_elems(M, N) floats. */
+long mgx_transpose_partial_elems(int M, int N);
+int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* colsum_partial, float* colsum_out, float colsum_beta,
+                       int M, int N, long ld_in, long in_rpb, long in_bstride, long ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ SIGNATURES = {
     "mgx_group_advantage": (_I, [_P, _P, _I, _I, _F, _F, _I, _P]),
     "mgx_global_advantage": (_I, [_P, _P, _P, _I, _I, _P]),
     "mgx_grpo_loss": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "mgx_gemm_bf16": (_I, [_P] * 6 + [_I, _I, _I] + [_L] * 8 + [_I, _F, _P]),
+    "mgx_transpose_partial_elems": (_L, [_I, _I]),
+    "mgx_transpose_bf16": (_I, [_P, _P, _P, _P, _F, _I, _I, _L, _L, _L, _L, _P]),
 }
 
 _lib = None

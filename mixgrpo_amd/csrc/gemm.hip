@@ -1,0 +1,339 @@
+// bf16 MFMA GEMM for the MMDiT linears (gfx950):  C[M,N] = epi( A[M,K] @ W[N,K]^T + bias )
+//
+// Both operands are K-contiguous ("NT"): activations [tokens, features] and torch Linear weights [out, in].
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16
+// accumulators.  Operands are staged global -> registers -> LDS (issue-early / write-late, one barrier per
+// K-tile, two LDS buffers); the LDS image is [row][64 k] with an XOR swizzle on the 16-byte chunk index
+// (chunk ^ ((row>>1)&7)) which makes every ds_read_b128 fragment read and every ds_write_b128 conflict-free.
+// The MFMA is issued with the weight fragment as the A operand so that each lane ends up with 4 consecutive
+// output features of one token: 8-byte bf16 stores, and bias/gate vectors are per-register constants.
+// blockIdx is remapped so that the 8 XCDs each own a contiguous band of tiles (private L2 reuse of W/A panels).
+//
+// "Row-batched" addressing (rpb, bstride) lets the text and image streams live inside one joint
+// [B, S, d] residual buffer: row m -> base + (m / rpb) * bstride + (m % rpb) * ld.
+#include "../../include/mixgrpo_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT = 256;
+
+struct RowMap {
+  long ld;       // elements between consecutive rows inside a batch
+  long rpb;      // rows per batch (>= M for a plain matrix)
+  long bstride;  // elements between batches
+};
+
+__device__ __forceinline__ long row_off(const RowMap& r, long m) {
+  const long b = m / r.rpb;
+  return b * r.bstride + (m - b * r.rpb) * r.ld;
+}
+
+enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2, EPI_F32_ACC = 3, EPI_BIAS_MULAUX = 4 };
+
+struct GemmArgs {
+  const bf16_raw* A;
+  const bf16_raw* W;
+  const bf16_raw* bias;   // [N] or null
+  void* C;                // bf16 (or fp32 for EPI_F32_ACC)
+  const bf16_raw* gate;   // [batches, gate_ld] (EPI_BIAS_GATE_RES): gate[b*gate_ld + n]
+  bf16_raw* aux;          // optional second output / input, same row map as C
+  long gate_ld;
+  int M, N, K;
+  RowMap a, c;
+  long ldw;
+  float beta;             // EPI_F32_ACC: C = beta*C + acc
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  const float t = tanhf(u);
+  const float du = k0 * (1.0f + 3.0f * k1 * x * x);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int EPI>
+__global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [buf][A|B][128 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // XCD-aware tile order: consecutive logical tiles (which share A/W panels) go to the same XCD
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // walk N fastest inside a band of 8 M-tiles so a wave of tiles reuses the same W panels and A panels
+  const int band = 8;
+  const int per_band = band * tiles_n;
+  const int b0 = bid / per_band;
+  const int rows_in_band = min(band, tiles_m - b0 * band);
+  const int in_band = bid - b0 * per_band;
+  const int tm = b0 * band + in_band % rows_in_band;
+  const int tn = in_band / rows_in_band;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+
+  // ---- loader setup: thread owns chunks c = tid + 256*i; row = c>>3 (+32*i), kc = c&7
+  const int lrow = tid >> 3, lkc = tid & 7;
+  // rows lrow + 32*i: (row>>1)&7 is the same for all four (32*i leaves bits 1..3 alone), so one LDS offset
+  auto a_ptr = [&](int i) {
+    long m = m0 + lrow + 32 * i;
+    if (m >= g.M) m = g.M - 1;
+    return g.A + row_off(g.a, m) + lkc * 8;
+  };
+  auto w_ptr = [&](int i) {
+    long n = n0 + lrow + 32 * i;
+    if (n >= g.N) n = g.N - 1;
+    return g.W + n * g.ldw + lkc * 8;
+  };
+  const bf16_raw* ap0 = a_ptr(0); const bf16_raw* ap1 = a_ptr(1); const bf16_raw* ap2 = a_ptr(2); const bf16_raw* ap3 = a_ptr(3);
+  const bf16_raw* wp0 = w_ptr(0); const bf16_raw* wp1 = w_ptr(1); const bf16_raw* wp2 = w_ptr(2); const bf16_raw* wp3 = w_ptr(3);
+  const int lds0 = lrow * 128 + swz(lrow, lkc) * 16;
+  uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define LOAD_TILE(kt)                                                            \
+  do {                                                                           \
+    const long ko = (long)(kt) * BK;                                             \
+    ra0 = *reinterpret_cast<const uint4*>(ap0 + ko);                             \
+    ra1 = *reinterpret_cast<const uint4*>(ap1 + ko);                             \
+    ra2 = *reinterpret_cast<const uint4*>(ap2 + ko);                             \
+    ra3 = *reinterpret_cast<const uint4*>(ap3 + ko);                             \
+    rw0 = *reinterpret_cast<const uint4*>(wp0 + ko);                             \
+    rw1 = *reinterpret_cast<const uint4*>(wp1 + ko);                             \
+    rw2 = *reinterpret_cast<const uint4*>(wp2 + ko);                             \
+    rw3 = *reinterpret_cast<const uint4*>(wp3 + ko);                             \
+  } while (0)
+#define STORE_TILE(buf)                                                          \
+  do {                                                                           \
+    char* base_ = smem + (buf) * 32768 + lds0;                                   \
+    *reinterpret_cast<uint4*>(base_) = ra0;                                      \
+    *reinterpret_cast<uint4*>(base_ + 4096) = ra1;                               \
+    *reinterpret_cast<uint4*>(base_ + 8192) = ra2;                               \
+    *reinterpret_cast<uint4*>(base_ + 12288) = ra3;                              \
+    *reinterpret_cast<uint4*>(base_ + 16384) = rw0;                              \
+    *reinterpret_cast<uint4*>(base_ + 16384 + 4096) = rw1;                       \
+    *reinterpret_cast<uint4*>(base_ + 16384 + 8192) = rw2;                       \
+    *reinterpret_cast<uint4*>(base_ + 16384 + 12288) = rw3;                      \
+  } while (0)
+
+  f32x4 acc[4][4];  // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nkt = g.K / BK;
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) LOAD_TILE(kt + 1);
+    const char* sa = smem + cur * 32768;
+    const char* sw = sa + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ra_ = wm * 64 + t * 16 + fr;
+        const int rw_ = wn * 64 + t * 16 + fr;
+        fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
+        fw[t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) STORE_TILE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= g.M) continue;
+    const long crow = row_off(g.c, m);
+    const long bidx = m / g.c.rpb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long n = n0 + wn * 64 + i * 16 + fq * 4;
+      if (n >= g.N) continue;   // N is a multiple of 4 (checked on the host)
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (EPI == EPI_F32_ACC) {
+        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + crow + n);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.beta != 0.f) {
+          const float4 old = *cp;
+          o.x += g.beta * old.x; o.y += g.beta * old.y; o.z += g.beta * old.z; o.w += g.beta * old.w;
+        }
+        *cp = o;
+        continue;
+      }
+      if (g.bias) {
+        const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the Linear's bf16 output
+      bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + n;
+      if (EPI == EPI_BIAS_GELU) {
+        if (g.aux) {  // keep the pre-activation for the backward pass
+          uint2 pre;
+          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(g.aux + crow + n) = pre;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+      } else if (EPI == EPI_BIAS_GATE_RES) {
+        if (g.aux) {  // pre-gate branch output, needed for d(gate)
+          uint2 pre;
+          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(g.aux + crow + n) = pre;
+        }
+        const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
+        const uint2 rr = *reinterpret_cast<const uint2*>(cp);
+        v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
+        v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
+        v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
+        v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
+      } else if (EPI == EPI_BIAS_MULAUX) {
+        // dgrad through GELU: C = (A@W^T) * gelu'(aux)   (aux = saved pre-activation)
+        const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + crow + n);
+        v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
+        v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
+      }
+      uint2 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *reinterpret_cast<uint2*>(cp) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ transpose
+// out[n][m] = in[m][n] (bf16), in rows row-batched, out [N][ldo] with ldo >= M (zero padded up to ldo by the
+// host memset).  Optionally emits per-block column partial sums (for bias gradients): part[blockIdx.y][n].
+__global__ void __launch_bounds__(256) transpose_kernel(const bf16_raw* __restrict__ in, bf16_raw* __restrict__ out,
+                                                        float* __restrict__ part, int M, int N, RowMap im, long ldo) {
+  __shared__ bf16_raw tile[64][66];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const long m = m0 + r;
+    const int n = n0 + tx;
+    bf16_raw v = 0;
+    if (m < M && n < N) v = in[row_off(im, m) + n];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r;
+    const long m = m0 + tx;
+    if (n < N && m < ldo) out[(long)n * ldo + m] = (m < M) ? tile[tx][r] : (bf16_raw)0;
+  }
+  if (part && m0 < M) {
+    if (ty == 0) {
+      float s = 0.f;
+      for (int r = 0; r < 64; ++r) s += bf2f(tile[r][tx]);
+      if (n0 + tx < N) part[(long)blockIdx.y * N + n0 + tx] = s;
+    }
+  }
+}
+
+__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N, float beta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * N + n];
+  out[n] = beta * out[n] + s;
+}
+
+template <int EPI>
+int launch(const GemmArgs& g, hipStream_t st) {
+  const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+  gemm_kernel<EPI><<<tiles, NT, 65536, st>>>(g);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+}  // namespace
+
+extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
+                             uint16_t* aux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                             long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream) {
+  MGX_REQUIRE(A && W && C, "null operand");
+  MGX_REQUIRE(M > 0 && N > 0 && K > 0, "empty GEMM");
+  MGX_REQUIRE(K % BK == 0, "K must be a multiple of 64");
+  MGX_REQUIRE(N % 4 == 0, "N must be a multiple of 4");
+  MGX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "leading dimensions must keep 16-byte row alignment");
+  MGX_REQUIRE(a_rpb > 0 && c_rpb > 0, "rows-per-batch must be positive");
+  MGX_REQUIRE(a_bstride % 8 == 0 && c_bstride % 4 == 0, "batch strides must keep alignment");
+  MGX_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 8 == 0), "operands must be 16-byte aligned");
+  GemmArgs g;
+  g.A = A; g.W = W; g.bias = bias; g.C = C; g.gate = gate; g.aux = aux; g.gate_ld = gate_ld;
+  g.M = M; g.N = N; g.K = K;
+  g.a = RowMap{lda, a_rpb, a_bstride};
+  g.c = RowMap{ldc, c_rpb, c_bstride};
+  g.ldw = ldw;
+  g.beta = beta;
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)gemm_kernel<EPI_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_MULAUX>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  switch (epilogue) {
+    case EPI_BIAS: return launch<EPI_BIAS>(g, st);
+    case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU>(g, st);
+    case EPI_BIAS_GATE_RES:
+      MGX_REQUIRE(gate, "gate-residual epilogue needs a gate");
+      return launch<EPI_BIAS_GATE_RES>(g, st);
+    case EPI_F32_ACC: return launch<EPI_F32_ACC>(g, st);
+    case EPI_BIAS_MULAUX:
+      MGX_REQUIRE(aux, "gelu-backward epilogue needs the saved pre-activation");
+      return launch<EPI_BIAS_MULAUX>(g, st);
+  }
+  mgx_set_error("unknown GEMM epilogue");
+  return MGX_ERR_ARG;
+}
+
+extern "C" long mgx_transpose_partial_elems(int M, int N) { return (long)cdiv(M, 64) * N; }
+
+extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* colsum_partial, float* colsum_out,
+                                  float colsum_beta, int M, int N, long ld_in, long in_rpb, long in_bstride, long ld_out,
+                                  void* stream) {
+  MGX_REQUIRE(in && out && M > 0 && N > 0, "bad argument");
+  MGX_REQUIRE(ld_out >= M, "output leading dimension must cover M");
+  MGX_REQUIRE((colsum_partial == nullptr) == (colsum_out == nullptr), "column sums need both workspace and output");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
+  transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
+  if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
