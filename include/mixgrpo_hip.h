@@ -151,6 +151,66 @@ long mgx_transpose_partial_elems(int M, int N);
 int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* colsum_partial, float* colsum_out, float colsum_beta,
                        int M, int N, long ld_in, long in_rpb, long in_bstride, long ld_out, void* stream);
 
+/* y[M, D] = bf16( LayerNorm(x[m,:]; eps 1e-6, no affine) * bf16(1 + scale[b,:]) + shift[b,:] ), b = m / x_rpb
+ * (AdaLayerNormZero / ...Single / ...Continuous normalisation).  shift/scale point at their chunk inside the
+ * modulation vector [B, mod_ld].  stats (optional) receives (mean, rstd) per row.  D % 512 == 0, D <= 4096. */
+int mgx_ln_modulate_fwd(const uint16_t* x, long ldx, long x_rpb, long x_bstride, const uint16_t* shift,
+                        const uint16_t* scale, long mod_ld, uint16_t* y, long ldy, float* stats, long M, int D,
+                        void* stream);
+/* Backward of the above: dx (+)= dLN, dshift/dscale (bf16, [B, mod_ld] chunks) = per-batch column sums. */
+long mgx_ln_modulate_bwd_workspace(long M, long rpb, int D);
+int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t* x, long ldx, long x_rpb, long x_bstride,
+                        const uint16_t* scale, long mod_ld, uint16_t* dx, long lddx, long dx_rpb, long dx_bstride,
+                        int accumulate, uint16_t* dshift, uint16_t* dscale, float* ws, long M, int D, void* stream);
+
+/* Per-head RMSNorm(eps 1e-6, fp32 weight[128]) on q,k + interleaved-pair RoPE (fp32 cos/sin [S,128]) + head
+ * split: qkv [B*rows_per_batch, 3*H*128] -> Q,K [B,H,S,128] (rounded once to bf16), Vt [B,H,128,Sp], written
+ * at sequence positions s0 .. s0+rows_per_batch-1 of the joint sequence (diffusers FluxAttnProcessor2_0). */
+int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                         const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int H, int S, int Sp,
+                         int rows_per_batch, int s0, void* stream);
+long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch);
+int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                         const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dVt, uint16_t* dqkv,
+                         float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp, int rows_per_batch, int s0,
+                         void* stream);
+
+/* O = softmax(scale * Q K^T) V, non-causal, head_dim 128 (F.scaled_dot_product_attention under autocast):
+ * Q,K [B,H,S,128], Vt [B,H,128,Sp] (Sp = S rounded up to 64, padding finite), O [B,S,ldo] at column h*128,
+ * lse [B,H,S] (optional, natural log) for the backward pass. */
+int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H, int S,
+                 int Sp, long ldo, long o_bstride, float scale, void* stream);
+
+/* out[b, :] = bf16(x[b, :] @ W[N,K]^T + bias), 1 <= Bn <= 16 rows (temb MLPs, AdaLN modulation linears) */
+int mgx_skinny_linear(const uint16_t* x, long ldx, const uint16_t* W, long ldw, const uint16_t* bias, uint16_t* out,
+                      long ldo, int Bn, int N, int K, void* stream);
+/* dW[N,K] (fp32) += dout[Bn,N]^T x[Bn,K]; dbias[N] (fp32, optional) += column sums of dout */
+int mgx_skinny_wgrad(const uint16_t* dout, long ldd, const uint16_t* x, long ldx, float* dW, long ldw, float* dbias,
+                     int Bn, int N, int K, void* stream);
+/* bf16 elementwise: op 0 y=silu(a) | 1 y=b*silu'(a) | 2 y=a+b | 3 y+=a */
+int mgx_ew_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, long n, int op, void* stream);
+/* diffusers Timesteps(256, flip_sin_to_cos=True, shift 0): out[b] = bf16([cos(t_b f) | sin(t_b f)]) */
+int mgx_sincos_embed(const float* t, uint16_t* out, int Bn, void* stream);
+int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
+/* Backward of x + gate*y: dy = bf16(gate[b]*dout), dgate[b,:] = sum_rows dout*y (bf16) */
+long mgx_gate_bwd_workspace(long batches, long rows_per_batch, int D);
+int mgx_gate_bwd(const uint16_t* dout, long ldd, long d_bstride, const uint16_t* y, long ldy, const uint16_t* gate,
+                 long gate_ld, uint16_t* dy, long lddy, uint16_t* dgate, float* ws, int batches, long rows_per_batch,
+                 int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimizer
+ * out[0] = beta*out[0] + sum g^2 (fp64 two-stage reduction; ws >= mgx_sqnorm_workspace() doubles):
+ * the global grad norm of transformer.clip_grad_norm_ (train_grpo_flux.py:606). */
+long mgx_sqnorm_workspace(void);
+int mgx_sqnorm_f32(const float* g, long n, double* ws, float* out, float beta, void* stream);
+/* torch.optim.AdamW step (train_grpo_flux.py:715-721,607) on flat fp32 master weights, fused with the
+ * clip-by-global-norm scaling (gnorm_sq: device pointer to sum g^2 of the UNSCALED grads, or NULL for no
+ * clipping; grad_scale multiplies every gradient first, e.g. 1/world_size) and the bf16 compute-copy refresh. */
+int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm,
+                   float grad_scale, void* stream);
+int mgx_scale_f32(float* x, long n, float s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,246 @@
+// Joint text+image attention for the FLUX MMDiT (non-causal, no mask, head_dim 128) -- forward.
+//
+// Replaces F.scaled_dot_product_attention as called by diffusers' FluxAttnProcessor2_0 under autocast(bf16)
+// (reference call sites fastvideo/utils/sampling_utils.py:68-82, train_grpo_flux.py:134-144).
+//
+// Layout: Q, K [B, H, S, 128] bf16 (RMS-normed + RoPE'd by qk_norm_rope), V transposed Vt [B, H, 128, Sp] bf16
+// (Sp = S rounded up to 64, padding finite).  Output O [B, S, ldo] bf16 at column h*128 (ldo = d or 5d).
+//
+// Structure (CDNA4, wave64): one workgroup = 8 waves = 256 query rows of one (b, h); each wave owns 32 queries.
+// K/V tiles of 64 keys go global -> registers -> LDS (issue-early / write-late, two LDS buffers, one barrier per
+// tile).  S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with K as the A operand, so a lane holds one query column
+// and 16 of the 32 keys of a block: the softmax row statistics are lane-local plus ONE exchange with lane^32.
+// The S^T accumulator is converted in place to the B operand of O^T += Vt P^T (accumulator-as-operand, no LDS
+// round trip); Vt is read from LDS with the matching permuted key order.  LDS images are XOR-swizzled so the
+// ds_read_b128 (K) and ds_read_b64 (Vt) fragment reads are bank-conflict free.
+#include "../../include/mixgrpo_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int QW = 32;            // queries per wave
+constexpr int NW = 8;             // waves per workgroup
+constexpr int QB = QW * NW;       // 256 queries per workgroup
+constexpr int KB = 64;            // keys per tile
+constexpr int K_TILE_BYTES = KB * HD * 2;   // 16 KiB
+constexpr int V_TILE_BYTES = HD * KB * 2;   // 16 KiB
+
+struct AttnArgs {
+  const bf16_raw* Q;
+  const bf16_raw* K;
+  const bf16_raw* Vt;
+  bf16_raw* O;
+  float* lse;      // [B, H, S] natural-log LSE of scale*scores (for the backward), may be null
+  int B, H, S, Sp;
+  long ldo;        // elements between consecutive tokens of O
+  long o_bstride;  // elements between batches of O
+  float scale_log2e;
+};
+
+// K tile image: [64 keys][16 chunks of 16 B], chunk ^= key & 15
+__device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }
+// Vt tile image: [128 d][16 chunks of 8 B], chunk ^= (d >> 1) & 15
+__device__ __forceinline__ int v_off(int d, int chunk8) { return d * 128 + ((chunk8 ^ ((d >> 1) & 15)) << 3); }
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+
+__global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | Vt tile]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int nq = (g.S + QB - 1) / QB;
+  // XCD-aware order: the q-tiles of one (b, head) stay on one XCD so its K/V stay in that L2
+  const int nwg = nq * g.H * g.B;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int qt = bid % nq;
+  const int bh = bid / nq;
+  const int b = bh / g.H, hh = bh - b * g.H;
+
+  const bf16_raw* Qp = g.Q + (long)bh * g.S * HD;
+  const bf16_raw* Kp = g.K + (long)bh * g.S * HD;
+  const bf16_raw* Vp = g.Vt + (long)bh * HD * g.Sp;
+
+  // ---- this wave's Q fragments (B operand of S^T = K Q^T): Q[q0 + r][16*ks + 8*h + j]
+  const int q0 = qt * QB + wid * QW;
+  int qrow = q0 + r;
+  if (qrow >= g.S) qrow = g.S - 1;
+  s16x8 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    qf[ks] = *reinterpret_cast<const s16x8*>(Qp + (long)qrow * HD + ks * 16 + h * 8);
+
+  // ---- staging: K tile = 1024 16-B chunks, Vt tile = 1024 16-B chunks; 512 threads -> 2 + 2 each
+  const int kc_key0 = tid >> 4, kc_chunk = tid & 15;          // chunk id = tid (+512): key = id>>4
+  const int vc_d0 = tid >> 3, vc_chunk = tid & 7;             // chunk id = tid (+512): d = id>>3, 16-B chunk of 64 keys
+  uint4 sk0, sk1, sv0, sv1;
+  const int ntiles = (g.S + KB - 1) / KB;
+#define LOAD_KV(t)                                                                                  \
+  do {                                                                                              \
+    const int key_base = (t) * KB;                                                                  \
+    int ka = key_base + kc_key0, kb_ = key_base + kc_key0 + 32;                                     \
+    if (ka >= g.S) ka = g.S - 1;                                                                    \
+    if (kb_ >= g.S) kb_ = g.S - 1;                                                                  \
+    sk0 = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                       \
+    sk1 = *reinterpret_cast<const uint4*>(Kp + (long)kb_ * HD + kc_chunk * 8);                      \
+    sv0 = *reinterpret_cast<const uint4*>(Vp + (long)vc_d0 * g.Sp + key_base + vc_chunk * 8);        \
+    sv1 = *reinterpret_cast<const uint4*>(Vp + (long)(vc_d0 + 64) * g.Sp + key_base + vc_chunk * 8); \
+  } while (0)
+#define STORE_KV(buf)                                                                               \
+  do {                                                                                              \
+    char* kb_ptr = smem + (buf) * (K_TILE_BYTES + V_TILE_BYTES);                                    \
+    char* vb_ptr = kb_ptr + K_TILE_BYTES;                                                           \
+    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0, kc_chunk)) = sk0;                             \
+    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0 + 32, kc_chunk)) = sk1;                        \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0, 2 * vc_chunk)) = make_uint2(sv0.x, sv0.y);      \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0, 2 * vc_chunk + 1)) = make_uint2(sv0.z, sv0.w);  \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + 64, 2 * vc_chunk)) = make_uint2(sv1.x, sv1.y); \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + 64, 2 * vc_chunk + 1)) = make_uint2(sv1.z, sv1.w); \
+  } while (0)
+
+  f32x16 o[4];   // O^T tiles: d in [32*dt, 32*dt+32), column = query r
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -INFINITY;   // running max of raw scores (shared by both half-waves)
+  float l_run = 0.f;         // this lane's partial row sum
+
+  LOAD_KV(0);
+  STORE_KV(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) LOAD_KV(t + 1);
+    const char* ks_ = smem + cur * (K_TILE_BYTES + V_TILE_BYTES);
+    const char* vs_ = ks_ + K_TILE_BYTES;
+
+    // ---- S^T blocks (32 keys x 32 queries) x 2
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const s16x8 kf = *reinterpret_cast<const s16x8*>(ks_ + k_off(kb * 32 + r, ks * 2 + h));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask keys beyond S (last tile only)
+    const int key_base = t * KB;
+    if (key_base + KB > g.S) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= g.S) s[kb][i] = -INFINITY;
+        }
+    }
+    // ---- online softmax (lane = one query; 32 of the tile's 64 keys here, 32 in lane^32)
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * g.scale_log2e);   // m_run = -inf on the first tile -> 0
+    const float mc = m_new * g.scale_log2e;
+    m_run = m_new;
+    float psum = 0.f;
+    uint32_t pb[2][8];   // P^T as bf16 pairs: B-operand fragments, k-step s uses regs 8s..8s+7
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const float p0 = exp2f(s[kb][i] * g.scale_log2e - mc);
+        const float p1 = exp2f(s[kb][i + 1] * g.scale_log2e - mc);
+        psum += p0 + p1;
+        pb[kb][i >> 1] = pack_bf16(p0, p1);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+
+    // ---- O^T += Vt P^T : A = Vt[d = 32*dt + r][keys in the accumulator's permuted order]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        s16x8 pf;
+        {
+          const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
+          pf = __builtin_bit_cast(s16x8, u);
+        }
+        // keys (within the tile) kb*32 + 16*s2 + 4h + {0..3} and +8
+        const int c8 = (kb * 32 + 16 * s2 + 4 * h) >> 2;   // 8-byte chunk index (4 keys per chunk)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int d = dt * 32 + r;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8));
+          const uint2 hi = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8 + 2));
+          const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, u), pf, o[dt], 0, 0, 0);
+        }
+      }
+    if (t + 1 < ntiles) STORE_KV(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- finalize: row sum across the two half-waves, normalise, store O[q][h*128 + d]
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < g.S) {
+    bf16_raw* op = g.O + (long)b * g.o_bstride + (long)q * g.ldo + hh * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int d = dt * 32 + 8 * i4 + 4 * h;
+        uint2 w;
+        w.x = pack_bf16(o[dt][4 * i4] * inv, o[dt][4 * i4 + 1] * inv);
+        w.y = pack_bf16(o[dt][4 * i4 + 2] * inv, o[dt][4 * i4 + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+    if (g.lse && h == 0) {
+      // ln sum_k exp(scale*s_k) = m*scale + ln(l)
+      g.lse[(long)bh * g.S + q] = m_run * (g.scale_log2e * 0.6931471805599453f) + logf(l_tot);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
+                            int H, int S, int Sp, long ldo, long o_bstride, float scale, void* stream) {
+  MGX_REQUIRE(Q && K && Vt && O, "null operand");
+  MGX_REQUIRE(B > 0 && H > 0 && S > 0, "empty attention");
+  MGX_REQUIRE(Sp >= S && Sp % 64 == 0, "Sp must be S rounded up to a multiple of 64");
+  MGX_REQUIRE(ldo % 4 == 0 && o_bstride % 4 == 0, "output strides must keep 8-byte alignment");
+  AttnArgs g;
+  g.Q = Q; g.K = K; g.Vt = Vt; g.O = O; g.lse = lse;
+  g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
+  g.scale_log2e = scale * 1.4426950408889634f;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr = true;
+  }
+  const int nq = cdiv(S, QB);
+  attn_fwd_kernel<<<nq * H * B, NW * 64, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

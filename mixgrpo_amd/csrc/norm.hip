@@ -1,0 +1,444 @@
+// HBM-bound normalisation kernels of the FLUX MMDiT (d = 3072 rows, head_dim 128), forward and backward:
+//   * AdaLN modulate: y = bf16( LayerNorm(x; eps 1e-6, no affine) * bf16(1 + scale[b]) + shift[b] )
+//   * QK RMSNorm (learned weight[128], eps 1e-6) + RoPE (interleaved pairs) + head split, and V transposition
+// All loads/stores are 16-byte vectors; one wave per row (LayerNorm) or per (token, head) (RMSNorm).
+// Replaces diffusers' AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous normalisation parts,
+// RMSNorm (norm_q/norm_k/norm_added_q/norm_added_k) and apply_rotary_emb inside FluxAttnProcessor2_0.
+#include "../../include/mixgrpo_hip.h"
+#include "common.h"
+
+namespace {
+
+struct RowMap {
+  long ld, rpb, bstride;
+};
+__device__ __forceinline__ long row_off(const RowMap& r, long m) {
+  const long b = m / r.rpb;
+  return b * r.bstride + (m - b * r.rpb) * r.ld;
+}
+
+constexpr int LN_MAXV = 8;   // up to 8 x 8 elements per lane = 4096 columns
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
+  f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  return u;
+}
+
+// ------------------------------------------------------------------------------------- LN-modulate forward
+// one wave per row; D = 8 * 64 * NV columns handled as NV vectors of 8 per lane (D % 512 == 0)
+template <int NV>
+__global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const bf16_raw* __restrict__ x, RowMap xm,
+                                                         const bf16_raw* __restrict__ shift,
+                                                         const bf16_raw* __restrict__ scale, long mod_ld,
+                                                         bf16_raw* __restrict__ y, long ldy, float* __restrict__ stats,
+                                                         long M) {
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63;
+  const long b = m / xm.rpb;
+  const bf16_raw* xr = x + row_off(xm, m);
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    unpack8(*reinterpret_cast<const uint4*>(xr + (i * 64 + lane) * 8), v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[i][j];
+  }
+  const float D = (float)(NV * 512);
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[i][j] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(q) / D + 1e-6f);
+  if (stats && lane == 0) {
+    stats[2 * m] = mean;
+    stats[2 * m + 1] = rstd;
+  }
+  const bf16_raw* sh = shift + b * mod_ld;
+  const bf16_raw* sc = scale + b * mod_ld;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    float fs[8], fc[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(sh + c), fs);
+    unpack8(*reinterpret_cast<const uint4*>(sc + c), fc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * rbf(1.0f + fc[j]) + fs[j];
+    *reinterpret_cast<uint4*>(y + m * ldy + c) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------------------------- LN-modulate backward
+// dy [M, D] -> dx accumulated into the residual-stream gradient (row-batched, bf16), and per-batch column sums
+// dshift[b, :] += sum_rows dy, dscale[b, :] += sum_rows dy * xhat (two-stage, deterministic).
+// Each block owns ROWS_PER_BLOCK consecutive rows of ONE batch; each wave walks rows w, w+4, ...
+constexpr int LN_BWD_ROWS = 32;
+template <int NV>
+__global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const bf16_raw* __restrict__ dy, long lddy,
+                                                         const bf16_raw* __restrict__ x, RowMap xm,
+                                                         const bf16_raw* __restrict__ scale, long mod_ld,
+                                                         bf16_raw* __restrict__ dx, RowMap dxm, int accumulate,
+                                                         float* __restrict__ part, long M, int blocks_per_batch) {
+  extern __shared__ float red[];   // [2][D]
+  const int D = NV * 512;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long b = blockIdx.x / blocks_per_batch;
+  const long r0 = (long)(blockIdx.x % blocks_per_batch) * LN_BWD_ROWS;
+  const bf16_raw* sc = scale + b * mod_ld;
+  float a_sh[NV][8], a_sc[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_sh[i][j] = a_sc[i][j] = 0.f;
+
+  for (int rr = w; rr < LN_BWD_ROWS; rr += 4) {
+    const long rb = r0 + rr;
+    if (rb >= xm.rpb) break;
+    const long m = b * xm.rpb + rb;
+    if (m >= M) break;
+    const bf16_raw* xr = x + row_off(xm, m);
+    float v[NV][8], g[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + (i * 64 + lane) * 8), v[i]);
+      unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + (i * 64 + lane) * 8), g[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+    const float Df = (float)D;
+    const float mean = wave_sum(s) / Df;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(q) / Df + 1e-6f);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float fc[8];
+      unpack8(*reinterpret_cast<const uint4*>(sc + (i * 64 + lane) * 8), fc);   // L1/L2 resident
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (v[i][j] - mean) * rstd;
+        const float gx = g[i][j] * rbf(1.0f + fc[j]);   // d/dxhat
+        a_sh[i][j] += g[i][j];
+        a_sc[i][j] += g[i][j] * xh;
+        c1 += gx;
+        c2 += gx * xh;
+        v[i][j] = xh;
+        g[i][j] = gx;
+      }
+    }
+    c1 = wave_sum(c1) / Df;
+    c2 = wave_sum(c2) / Df;
+    bf16_raw* dxr = dx + row_off(dxm, m);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - c1 - v[i][j] * c2);
+      uint4* p = reinterpret_cast<uint4*>(dxr + (i * 64 + lane) * 8);
+      if (accumulate) {
+        float old[8];
+        unpack8(*p, old);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += old[j];
+      }
+      *p = pack8(o);
+    }
+  }
+  // combine the 4 waves' column sums wave after wave in one [2][D] LDS image, emit one partial row per block
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = (i * 64 + lane) * 8 + j;
+          if (ww == 0) { red[c] = a_sh[i][j]; red[D + c] = a_sc[i][j]; }
+          else { red[c] += a_sh[i][j]; red[D + c] += a_sc[i][j]; }
+        }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < 2 * D; c += 256) part[(long)blockIdx.x * 2 * D + c] = red[c];
+}
+
+// dshift[b, c] (+)= sum over the batch's blocks; gradients are bf16 [B, mod_ld] chunks of the modulation vector
+__global__ void ln_mod_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dshift,
+                                         bf16_raw* __restrict__ dscale, long mod_ld, int D, int blocks_per_batch) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < blocks_per_batch; ++k) {
+    const long blk = (long)b * blocks_per_batch + k;
+    s0 += part[(blk * 2 + 0) * D + c];
+    s1 += part[(blk * 2 + 1) * D + c];
+  }
+  dshift[(long)b * mod_ld + c] = f2bf(s0);
+  dscale[(long)b * mod_ld + c] = f2bf(s1);
+}
+
+// ------------------------------------------------------------------------------------- QK norm + RoPE + split
+// qkv [rows, 3*H*128] (q | k | v per token, plain matrix of one stream) -> Q, K [B, H, S, 128], Vt [B, H, 128, Sp]
+// Block = 64 tokens x 1 head; 4 waves: each wave 16 tokens; lane = one rotation pair (2 elements).
+struct QkArgs {
+  const bf16_raw* qkv;
+  long ld;            // 3*H*128
+  const float* wq;    // [128] fp32 RMSNorm weights
+  const float* wk;
+  const float* cos;   // [S, 128] fp32
+  const float* sin;
+  bf16_raw* Q;
+  bf16_raw* K;
+  bf16_raw* Vt;
+  int H, S, Sp;
+  int rows_per_batch;  // tokens of this stream per sample
+  int s0;              // position of the stream's first token in the joint sequence
+};
+
+__global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
+  __shared__ bf16_raw vt[64][130];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hh = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int HD = 128;
+  const long dmodel = (long)a.H * HD;
+  const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
+  const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
+  for (int i = 0; i < 16; ++i) {
+    const int tl = w * 16 + i;
+    const int t = t0 + tl;
+    if (t >= a.rows_per_batch) break;
+    const long row = (long)b * a.rows_per_batch + t;
+    const int s = a.s0 + t;
+    const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
+    const uint32_t uq = *reinterpret_cast<const uint32_t*>(base);
+    const uint32_t uk = *reinterpret_cast<const uint32_t*>(base + dmodel);
+    const uint32_t uv = *reinterpret_cast<const uint32_t*>(base + 2 * dmodel);
+    *reinterpret_cast<uint32_t*>(&vt[tl][2 * lane]) = uv;
+    const float c0 = a.cos[(long)s * HD + 2 * lane], c1 = a.cos[(long)s * HD + 2 * lane + 1];
+    const float s0 = a.sin[(long)s * HD + 2 * lane], s1 = a.sin[(long)s * HD + 2 * lane + 1];
+    const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
+    {
+      const float x0 = bf2f(uq & 0xffff), x1 = bf2f(uq >> 16);
+      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+      const float y0 = x0 * r * wq0, y1 = x1 * r * wq1;
+      *reinterpret_cast<uint32_t*>(a.Q + o) = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+    }
+    {
+      const float x0 = bf2f(uk & 0xffff), x1 = bf2f(uk >> 16);
+      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+      const float y0 = x0 * r * wk0, y1 = x1 * r * wk1;
+      *reinterpret_cast<uint32_t*>(a.K + o) = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+    }
+  }
+  __syncthreads();
+  // transposed V: Vt[b, h, d, s0 + t0 + 0..63] <- vt[t][d]; thread -> (d = id>>2.., 16 tokens chunk)
+  const int ntok = min(64, a.rows_per_batch - t0);
+  for (int id = threadIdx.x; id < 128 * 8; id += 256) {
+    const int d = id >> 3, c = id & 7;   // 8 tokens per 16-byte chunk
+    bf16_raw* dst = a.Vt + (((long)b * a.H + hh) * HD + d) * a.Sp + a.s0 + t0 + c * 8;
+    if (c * 8 + 8 <= ntok && (((a.s0 + t0) & 7) == 0)) {
+      uint4 u;
+      u.x = (uint32_t)vt[c * 8 + 0][d] | ((uint32_t)vt[c * 8 + 1][d] << 16);
+      u.y = (uint32_t)vt[c * 8 + 2][d] | ((uint32_t)vt[c * 8 + 3][d] << 16);
+      u.z = (uint32_t)vt[c * 8 + 4][d] | ((uint32_t)vt[c * 8 + 5][d] << 16);
+      u.w = (uint32_t)vt[c * 8 + 6][d] | ((uint32_t)vt[c * 8 + 7][d] << 16);
+      *reinterpret_cast<uint4*>(dst) = u;
+    } else {
+      for (int j = 0; j < 8; ++j)
+        if (c * 8 + j < ntok) dst[j] = vt[c * 8 + j][d];
+    }
+  }
+}
+
+// backward: dQ, dK [B,H,S,128], dVt [B,H,128,Sp] -> dqkv [rows, 3*H*128]; per-block partial weight grads
+struct QkBwdArgs {
+  const bf16_raw* qkv;
+  long ld;
+  const float* wq;
+  const float* wk;
+  const float* cos;
+  const float* sin;
+  const bf16_raw* dQ;
+  const bf16_raw* dK;
+  const bf16_raw* dVt;
+  bf16_raw* dqkv;
+  float* part;     // [nblocks][2][128]
+  int H, S, Sp, rows_per_batch, s0;
+};
+
+__global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
+  __shared__ bf16_raw vt[128][66];
+  __shared__ float red[4][2][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hh = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int HD = 128;
+  const long dmodel = (long)a.H * HD;
+  const int ntok = min(64, a.rows_per_batch - t0);
+  // stage dVt tile [128 d][64 tokens]
+  for (int id = threadIdx.x; id < 128 * 64; id += 256) {
+    const int d = id >> 6, tt = id & 63;
+    bf16_raw v = 0;
+    if (tt < ntok) v = a.dVt[(((long)b * a.H + hh) * HD + d) * a.Sp + a.s0 + t0 + tt];
+    vt[d][tt] = v;
+  }
+  __syncthreads();
+  const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
+  const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
+  float gq0 = 0.f, gq1 = 0.f, gk0 = 0.f, gk1 = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    const int tl = w * 16 + i;
+    const int t = t0 + tl;
+    if (t >= a.rows_per_batch) break;
+    const long row = (long)b * a.rows_per_batch + t;
+    const int s = a.s0 + t;
+    const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
+    bf16_raw* obase = a.dqkv + row * a.ld + hh * HD + 2 * lane;
+    const float c0 = a.cos[(long)s * HD + 2 * lane], c1 = a.cos[(long)s * HD + 2 * lane + 1];
+    const float s0 = a.sin[(long)s * HD + 2 * lane], s1 = a.sin[(long)s * HD + 2 * lane + 1];
+    const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const uint32_t ux = *reinterpret_cast<const uint32_t*>(base + which * dmodel);
+      const uint32_t ug = *reinterpret_cast<const uint32_t*>((which ? a.dK : a.dQ) + o);
+      const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
+      const float x0 = bf2f(ux & 0xffff), x1 = bf2f(ux >> 16);
+      const float go0 = bf2f(ug & 0xffff), go1 = bf2f(ug >> 16);
+      // rope^T: out0 = y0 c0 - y1 s0 ; out1 = y1 c1 + y0 s1
+      const float gy0 = go0 * c0 + go1 * s1;
+      const float gy1 = -go0 * s0 + go1 * c1;
+      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+      // y = x * r * w
+      if (which) { gk0 += gy0 * x0 * r; gk1 += gy1 * x1 * r; } else { gq0 += gy0 * x0 * r; gq1 += gy1 * x1 * r; }
+      const float gz0 = gy0 * w0, gz1 = gy1 * w1;           // grad wrt (x*r)
+      const float dot = wave_sum(gz0 * x0 + gz1 * x1) / 128.f;
+      const float dx0 = r * gz0 - x0 * r * r * r * dot;
+      const float dx1 = r * gz1 - x1 * r * r * r * dot;
+      *reinterpret_cast<uint32_t*>(obase + which * dmodel) = (uint32_t)f2bf(dx0) | ((uint32_t)f2bf(dx1) << 16);
+    }
+    *reinterpret_cast<uint32_t*>(obase + 2 * dmodel) = (uint32_t)vt[2 * lane][tl] | ((uint32_t)vt[2 * lane + 1][tl] << 16);
+  }
+  red[w][0][2 * lane] = gq0; red[w][0][2 * lane + 1] = gq1;
+  red[w][1][2 * lane] = gk0; red[w][1][2 * lane + 1] = gk1;
+  __syncthreads();
+  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  {
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    a.part[(blk * 2 + which) * 128 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+__global__ void qk_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ gq, float* __restrict__ gk,
+                                     long nblocks) {
+  const int which = blockIdx.x, c = threadIdx.x;   // 2 blocks x 128 threads
+  float s = 0.f;
+  for (long k = 0; k < nblocks; ++k) s += part[(k * 2 + which) * 128 + c];
+  float* dst = which ? gk : gq;
+  dst[c] += s;
+}
+
+}  // namespace
+
+extern "C" int mgx_ln_modulate_fwd(const uint16_t* x, long ldx, long x_rpb, long x_bstride, const uint16_t* shift,
+                                   const uint16_t* scale, long mod_ld, uint16_t* y, long ldy, float* stats, long M, int D,
+                                   void* stream) {
+  MGX_REQUIRE(x && shift && scale && y && M > 0, "bad argument");
+  MGX_REQUIRE(D % 512 == 0 && D <= 4096, "feature size must be a multiple of 512 up to 4096");
+  MGX_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && mod_ld % 8 == 0 && x_bstride % 8 == 0, "16-byte row alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const RowMap xm{ldx, x_rpb, x_bstride};
+  const int grid = cdiv(M, 4);
+  switch (D / 512) {
+#define CASE(nv) case nv: ln_mod_fwd_kernel<nv><<<grid, 256, 0, st>>>(x, xm, shift, scale, mod_ld, y, ldy, stats, M); break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" long mgx_ln_modulate_bwd_workspace(long M, long rpb, int D) {
+  const long batches = (M + rpb - 1) / rpb;
+  const long bpb = ((rpb < M ? rpb : M) + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  return batches * bpb * 2 * D;
+}
+
+extern "C" int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t* x, long ldx, long x_rpb, long x_bstride,
+                                   const uint16_t* scale, long mod_ld, uint16_t* dx, long lddx, long dx_rpb,
+                                   long dx_bstride, int accumulate, uint16_t* dshift, uint16_t* dscale, float* ws, long M,
+                                   int D, void* stream) {
+  MGX_REQUIRE(dy && x && scale && dx && dshift && dscale && ws && M > 0, "bad argument");
+  MGX_REQUIRE(D % 512 == 0 && D <= 4096, "feature size must be a multiple of 512 up to 4096");
+  MGX_REQUIRE(x_rpb == dx_rpb, "x and dx must be batched alike");
+  hipStream_t st = (hipStream_t)stream;
+  const long rpb = x_rpb < M ? x_rpb : M;
+  const int batches = cdiv(M, rpb);
+  const int bpb = cdiv(rpb, LN_BWD_ROWS);
+  const RowMap xm{ldx, rpb, x_bstride}, dxm{lddx, rpb, dx_bstride};
+  const size_t lds = (size_t)2 * D * sizeof(float);
+  switch (D / 512) {
+#define CASE(nv)                                                                                                  \
+  case nv:                                                                                                        \
+    ln_mod_bwd_kernel<nv><<<batches * bpb, 256, lds, st>>>(dy, lddy, x, xm, scale, mod_ld, dx, dxm, accumulate, ws, M, bpb); \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  ln_mod_bwd_finish_kernel<<<dim3(cdiv(D, 256), batches), 256, 0, st>>>(ws, dshift, dscale, mod_ld, D, bpb);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                    const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int H, int S, int Sp,
+                                    int rows_per_batch, int s0, void* stream) {
+  MGX_REQUIRE(qkv && wq && wk && cos && sin && Q && K && Vt, "null argument");
+  MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Sp >= S, "bad sizes");
+  MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
+  QkArgs a{qkv, ld, wq, wk, cos, sin, Q, K, Vt, H, S, Sp, rows_per_batch, s0};
+  qk_norm_rope_fwd_kernel<<<dim3(cdiv(rows_per_batch, 64), H, B), 256, 0, (hipStream_t)stream>>>(a);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch) {
+  return (long)cdiv(rows_per_batch, 64) * H * B * 2 * 128;
+}
+
+extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                    const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dVt,
+                                    uint16_t* dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp,
+                                    int rows_per_batch, int s0, void* stream) {
+  MGX_REQUIRE(qkv && wq && wk && cos && sin && dQ && dK && dVt && dqkv && gwq && gwk && ws, "null argument");
+  MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
+  hipStream_t st = (hipStream_t)stream;
+  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dVt, dqkv, ws, H, S, Sp, rows_per_batch, s0};
+  dim3 grid(cdiv(rows_per_batch, 64), H, B);
+  qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
+  qk_bwd_finish_kernel<<<2, 128, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

@@ -1,0 +1,225 @@
+// Small-M ("skinny") linears and tiny elementwise ops of the conditioning path (temb, AdaLN modulation vectors):
+// M = batch (<= 16) rows against [N, K] weights.  These are weight-streaming, HBM-bound: each wave streams 16
+// weight rows straight from global memory into MFMA fragments (no LDS round trip, 4 K-steps in flight) and the
+// tiny activation matrix is read through L1.  Replaces the nn.Linear calls inside diffusers'
+// CombinedTimestepGuidanceTextProjEmbeddings and AdaLayerNormZero*/AdaLayerNormContinuous `.linear`.
+#include "../../include/mixgrpo_hip.h"
+#include "common.h"
+
+namespace {
+
+// out[b, n] = bf16( sum_k x[b,k] W[n,k] + bias[n] ),  b < Bn <= 16
+__global__ void __launch_bounds__(256) skinny_linear_kernel(const bf16_raw* __restrict__ x, long ldx,
+                                                            const bf16_raw* __restrict__ W, long ldw,
+                                                            const bf16_raw* __restrict__ bias,
+                                                            bf16_raw* __restrict__ out, long ldo, int Bn, int N, int K) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + w) * 16;
+  if (n0 >= N) return;
+  const int fr = lane & 15, fq = lane >> 4;
+  int nrow = n0 + fr;
+  if (nrow >= N) nrow = N - 1;
+  int brow = fr < Bn ? fr : Bn - 1;
+  const bf16_raw* wp = W + (long)nrow * ldw + fq * 8;
+  const bf16_raw* xp = x + (long)brow * ldx + fq * 8;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 128 <= K; k += 128) {
+    s16x8 a0 = *reinterpret_cast<const s16x8*>(wp + k), a1 = *reinterpret_cast<const s16x8*>(wp + k + 32);
+    s16x8 a2 = *reinterpret_cast<const s16x8*>(wp + k + 64), a3 = *reinterpret_cast<const s16x8*>(wp + k + 96);
+    s16x8 b0 = *reinterpret_cast<const s16x8*>(xp + k), b1 = *reinterpret_cast<const s16x8*>(xp + k + 32);
+    s16x8 b2 = *reinterpret_cast<const s16x8*>(xp + k + 64), b3 = *reinterpret_cast<const s16x8*>(xp + k + 96);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b3, acc, 0, 0, 0);
+  }
+  for (; k < K; k += 32) {
+    s16x8 a0 = *reinterpret_cast<const s16x8*>(wp + k);
+    s16x8 b0 = *reinterpret_cast<const s16x8*>(xp + k);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+  }
+  // D[i = n local][j = b]: lane holds b = fr, n = n0 + 4*fq + r
+  if (fr < Bn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * fq + r;
+      if (n < N) {
+        float v = acc[r];
+        if (bias) v += bf2f(bias[n]);
+        out[(long)fr * ldo + n] = f2bf(v);
+      }
+    }
+  }
+}
+
+// dW[n, k] += sum_b dout[b, n] * x[b, k]  (fp32 accumulate into the gradient buffer); dbias[n] += sum_b dout[b, n]
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const bf16_raw* __restrict__ dout, long ldd,
+                                                           const bf16_raw* __restrict__ x, long ldx,
+                                                           float* __restrict__ dW, long ldw, float* __restrict__ dbias,
+                                                           int Bn, int N, int K) {
+  const int n = blockIdx.y;
+  float dn[16];
+  float sb = 0.f;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    dn[b] = b < Bn ? bf2f(dout[(long)b * ldd + n]) : 0.f;
+    sb += dn[b];
+  }
+  if (dbias && blockIdx.x == 0 && threadIdx.x == 0) dbias[n] += sb;
+  for (int k = (blockIdx.x * 256 + threadIdx.x) * 4; k < K; k += gridDim.x * 256 * 4) {
+    float4 g = *reinterpret_cast<float4*>(dW + (long)n * ldw + k);
+    for (int b = 0; b < Bn; ++b) {
+      const uint2 u = *reinterpret_cast<const uint2*>(x + (long)b * ldx + k);
+      g.x += dn[b] * bf2f(u.x & 0xffff); g.y += dn[b] * bf2f(u.x >> 16);
+      g.z += dn[b] * bf2f(u.y & 0xffff); g.w += dn[b] * bf2f(u.y >> 16);
+    }
+    *reinterpret_cast<float4*>(dW + (long)n * ldw + k) = g;
+  }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// op: 0 silu fwd (y = bf16(silu(a))) | 1 silu bwd (y = bf16(b * silu'(a))) | 2 add (y = bf16(a + b))
+// 3 add-inplace-accumulate (y = bf16(y + a))
+__global__ void ew_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, bf16_raw* __restrict__ y,
+                          long n, int op) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float fa = bf2f(a[i]);
+    float r;
+    if (op == 0) r = silu_f(fa);
+    else if (op == 1) {
+      const float s = 1.0f / (1.0f + expf(-fa));
+      r = bf2f(b[i]) * (s * (1.0f + fa * (1.0f - s)));
+    } else if (op == 2) r = fa + bf2f(b[i]);
+    else r = bf2f(y[i]) + fa;
+    y[i] = f2bf(r);
+  }
+}
+
+// Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = bf16([cos(t f_k) | sin(t f_k)]), f_k = 10000^(-k/128)
+__global__ void sincos_embed_kernel(const float* __restrict__ t, bf16_raw* __restrict__ out, int Bn) {
+  const int b = blockIdx.x, k = threadIdx.x;   // 128 threads
+  if (b >= Bn) return;
+  const float f = expf(-logf(10000.0f) * (float)k / 128.0f);
+  const float ang = t[b] * f;
+  out[(long)b * 256 + k] = f2bf(cosf(ang));
+  out[(long)b * 256 + 128 + k] = f2bf(sinf(ang));
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_raw* __restrict__ y, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    uint2 o;
+    o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(y + i) = o;
+  }
+}
+
+// gate-residual backward helpers on [rows, D] row-batched streams:
+//   dgate[b, c] = sum_rows dout[m, c] * y[m, c]   (y = pre-gate branch output), dy[m, c] = bf16(gate[b, c] * dout[m, c])
+// Block = 32 rows of one batch x 256 columns... each thread owns 1 column pair across the block's rows.
+constexpr int GR_ROWS = 64;
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const bf16_raw* __restrict__ dout, long ldd, long d_rpb,
+                                                       long d_bstride, const bf16_raw* __restrict__ y, long ldy,
+                                                       const bf16_raw* __restrict__ gate, long gate_ld,
+                                                       bf16_raw* __restrict__ dy, long lddy, float* __restrict__ part,
+                                                       long rows_per_batch, int D, int blocks_per_batch) {
+  const long b = blockIdx.y / blocks_per_batch;
+  const long r0 = (long)(blockIdx.y % blocks_per_batch) * GR_ROWS;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= D) return;
+  const uint32_t gu = *reinterpret_cast<const uint32_t*>(gate + b * gate_ld + c);
+  const float g0 = bf2f(gu & 0xffff), g1 = bf2f(gu >> 16);
+  float a0 = 0.f, a1 = 0.f;
+  const long rend = min(r0 + (long)GR_ROWS, rows_per_batch);
+  for (long r = r0; r < rend; ++r) {
+    const long m = b * rows_per_batch + r;
+    const uint32_t du = *reinterpret_cast<const uint32_t*>(dout + b * d_bstride + r * ldd + c);
+    const uint32_t yu = *reinterpret_cast<const uint32_t*>(y + m * ldy + c);
+    const float d0 = bf2f(du & 0xffff), d1 = bf2f(du >> 16);
+    a0 += d0 * bf2f(yu & 0xffff);
+    a1 += d1 * bf2f(yu >> 16);
+    *reinterpret_cast<uint32_t*>(dy + m * lddy + c) = (uint32_t)f2bf(g0 * d0) | ((uint32_t)f2bf(g1 * d1) << 16);
+  }
+  part[(long)blockIdx.y * D + c] = a0;
+  part[(long)blockIdx.y * D + c + 1] = a1;
+}
+
+__global__ void gate_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dgate, long gate_ld, int D,
+                                       int blocks_per_batch) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (int k = 0; k < blocks_per_batch; ++k) s += part[((long)b * blocks_per_batch + k) * D + c];
+  dgate[(long)b * gate_ld + c] = f2bf(s);
+}
+
+}  // namespace
+
+extern "C" int mgx_skinny_linear(const uint16_t* x, long ldx, const uint16_t* W, long ldw, const uint16_t* bias,
+                                 uint16_t* out, long ldo, int Bn, int N, int K, void* stream) {
+  MGX_REQUIRE(x && W && out, "null operand");
+  MGX_REQUIRE(Bn >= 1 && Bn <= 16, "skinny linear handles 1..16 rows");
+  MGX_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "K must be a multiple of 32 with 16-byte aligned rows");
+  skinny_linear_kernel<<<cdiv(N, 64), 256, 0, (hipStream_t)stream>>>(x, ldx, W, ldw, bias, out, ldo, Bn, N, K);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_skinny_wgrad(const uint16_t* dout, long ldd, const uint16_t* x, long ldx, float* dW, long ldw,
+                                float* dbias, int Bn, int N, int K, void* stream) {
+  MGX_REQUIRE(dout && x && dW, "null operand");
+  MGX_REQUIRE(Bn >= 1 && Bn <= 16, "skinny wgrad handles 1..16 rows");
+  MGX_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "K must be a multiple of 4");
+  int gx = cdiv(K, 1024);
+  skinny_wgrad_kernel<<<dim3(gx, N), 256, 0, (hipStream_t)stream>>>(dout, ldd, x, ldx, dW, ldw, dbias, Bn, N, K);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_ew_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, long n, int op, void* stream) {
+  MGX_REQUIRE(a && y && n > 0 && op >= 0 && op <= 3, "bad argument");
+  MGX_REQUIRE(op == 0 || op == 3 || b, "binary op needs b");
+  int nb = cdiv(n, 256);
+  if (nb > 2048) nb = 2048;
+  ew_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(a, b, y, n, op);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_sincos_embed(const float* t, uint16_t* out, int Bn, void* stream) {
+  MGX_REQUIRE(t && out && Bn > 0, "bad argument");
+  sincos_embed_kernel<<<Bn, 128, 0, (hipStream_t)stream>>>(t, out, Bn);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream) {
+  MGX_REQUIRE(x && y && n > 0 && n % 4 == 0, "bad argument");
+  int nb = cdiv(n, 1024);
+  if (nb > 4096) nb = 4096;
+  cast_f32_bf16_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(x, y, n);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" long mgx_gate_bwd_workspace(long batches, long rows_per_batch, int D) {
+  return batches * ((rows_per_batch + GR_ROWS - 1) / GR_ROWS) * D;
+}
+
+extern "C" int mgx_gate_bwd(const uint16_t* dout, long ldd, long d_bstride, const uint16_t* y, long ldy,
+                            const uint16_t* gate, long gate_ld, uint16_t* dy, long lddy, uint16_t* dgate, float* ws,
+                            int batches, long rows_per_batch, int D, void* stream) {
+  MGX_REQUIRE(dout && y && gate && dy && dgate && ws, "null operand");
+  MGX_REQUIRE(D % 2 == 0 && batches > 0 && rows_per_batch > 0, "bad sizes");
+  const int bpb = cdiv(rows_per_batch, GR_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  gate_bwd_kernel<<<dim3(cdiv(D, 512), batches * bpb), 256, 0, st>>>(dout, ldd, rows_per_batch, d_bstride, y, ldy, gate,
+                                                                      gate_ld, dy, lddy, ws, rows_per_batch, D, bpb);
+  gate_bwd_finish_kernel<<<dim3(cdiv(D, 256), batches), 256, 0, st>>>(ws, dgate, gate_ld, D, bpb);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

@@ -1,0 +1,470 @@
+"""FLUX MMDiT on MI355X: drop-in for `diffusers.FluxTransformer2DModel` as the reference calls it
+(fastvideo/utils/sampling_utils.py:68-82, fastvideo/train_grpo_flux.py:134-144,606,677-679).
+
+Same call signature (kwargs), `.train()/.eval()/.parameters()/.state_dict()/.load_state_dict()/.config/
+.clip_grad_norm_()`, diffusers state-dict key names.  All arithmetic runs in the hand-written HIP kernels of
+csrc/ through the C ABI; this file is host orchestration: the flat parameter store, workspace reuse, the block
+schedule and (for training) block-level activation recompute in the backward pass.
+
+Precision policy = the reference's autocast(bf16) over fp32 master weights: bf16 compute copy of the weights,
+fp32 MFMA accumulation, bf16 residual stream, fp32 norm statistics, fp32 gradients for weights.
+
+Memory layout: ONE joint residual buffer X[B, S, d] (text rows first, S = L + N); the text / image streams of
+the double blocks are row-batched views of it (no concat/split copies).  Parameters live in one flat fp32
+buffer (+ a bf16 mirror with the identical element order) in which to_q|to_k|to_v are adjacent, so the fused
+QKV projection is a view.
+"""
+import json
+import math
+import os
+from dataclasses import asdict, dataclass
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import ops
+from ._lib import MgxError
+from .ops import BF16, F32, Rows, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES
+
+
+@dataclass
+class FluxConfig:
+    patch_size: int = 1
+    in_channels: int = 64
+    num_layers: int = 19
+    num_single_layers: int = 38
+    attention_head_dim: int = 128
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = True
+    axes_dims_rope: Tuple[int, int, int] = (16, 56, 56)
+
+    @property
+    def dim(self):
+        return self.attention_head_dim * self.num_attention_heads
+
+    def to_dict(self):
+        d = asdict(self)
+        d["axes_dims_rope"] = list(self.axes_dims_rope)
+        d["_class_name"] = "FluxTransformer2DModel"
+        return d
+
+
+def param_layout(cfg: FluxConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Flat order of the parameters (diffusers names).  q|k|v weights (and biases) are adjacent on purpose."""
+    d, hd = cfg.dim, cfg.attention_head_dim
+    out = []
+
+    def lin(name, o, i):
+        out.append((name + ".weight", (o, i)))
+        out.append((name + ".bias", (o,)))
+
+    def qkv(prefix, names):
+        for n in names:
+            out.append((f"{prefix}.{n}.weight", (d, d)))
+        for n in names:
+            out.append((f"{prefix}.{n}.bias", (d,)))
+
+    lin("x_embedder", d, cfg.in_channels)
+    lin("context_embedder", d, cfg.joint_attention_dim)
+    embs = ["timestep_embedder"] + (["guidance_embedder"] if cfg.guidance_embeds else []) + ["text_embedder"]
+    for e in embs:
+        lin(f"time_text_embed.{e}.linear_1", d, cfg.pooled_projection_dim if e == "text_embedder" else 256)
+        lin(f"time_text_embed.{e}.linear_2", d, d)
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}"
+        lin(f"{p}.norm1.linear", 6 * d, d)
+        lin(f"{p}.norm1_context.linear", 6 * d, d)
+        qkv(f"{p}.attn", ("to_q", "to_k", "to_v"))
+        qkv(f"{p}.attn", ("add_q_proj", "add_k_proj", "add_v_proj"))
+        lin(f"{p}.attn.to_out.0", d, d)
+        lin(f"{p}.attn.to_add_out", d, d)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            out.append((f"{p}.attn.{n}.weight", (hd,)))
+        for ff in ("ff", "ff_context"):
+            lin(f"{p}.{ff}.net.0.proj", 4 * d, d)
+            lin(f"{p}.{ff}.net.2", d, 4 * d)
+    for i in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{i}"
+        lin(f"{p}.norm.linear", 3 * d, d)
+        qkv(f"{p}.attn", ("to_q", "to_k", "to_v"))
+        lin(f"{p}.proj_mlp", 4 * d, d)
+        lin(f"{p}.proj_out", d, 5 * d)
+        for n in ("norm_q", "norm_k"):
+            out.append((f"{p}.attn.{n}.weight", (hd,)))
+    lin("norm_out.linear", 2 * d, d)
+    lin("proj_out", cfg.patch_size * cfg.patch_size * cfg.in_channels, d)
+    return out
+
+
+class ParamStore:
+    """Flat fp32 master + bf16 mirror (+ fp32 grad / Adam moments on demand), addressed by diffusers names."""
+
+    ALIGN = 64
+
+    def __init__(self, cfg: FluxConfig, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, shape in param_layout(cfg):
+            self.index[name] = (off, shape)
+            n = 1
+            for s in shape:
+                n *= s
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        self.w32 = torch.zeros(off, dtype=F32, device=self.device)
+        self.w16 = torch.zeros(off, dtype=BF16, device=self.device)
+        self.g32 = None
+
+    def view(self, buf, name):
+        off, shape = self.index[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def fused(self, buf, first, rows_total):
+        """View of `rows_total` rows starting at tensor `first` (adjacent tensors of equal width)."""
+        off, shape = self.index[first]
+        if len(shape) == 1:
+            return buf[off:off + rows_total]
+        return buf[off:off + rows_total * shape[1]].view(rows_total, shape[1])
+
+    def sync_bf16(self):
+        self.w16.copy_(self.w32)
+
+    def ensure_grad(self):
+        if self.g32 is None:
+            self.g32 = torch.zeros(self.numel, dtype=F32, device=self.device)
+        return self.g32
+
+    def init_synthetic(self, seed=0, std=0.02, bias_std=0.0):
+        """Random-init weights of the right architecture (no checkpoints offline): N(0, std^2) matrices, zero (or
+        N(0, bias_std^2)) biases, RMSNorm weights 1.  Generated on the device, tensor by tensor."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, (off, shape) in self.index.items():
+            v = self.view(self.w32, name)
+            if name.endswith(".bias"):
+                if bias_std > 0:
+                    v.normal_(0.0, bias_std, generator=g)
+                else:
+                    v.zero_()
+            elif len(shape) == 1:
+                v.fill_(1.0)
+                if bias_std > 0:
+                    v.add_(torch.randn(shape, generator=g, device=self.device) * bias_std)
+            else:
+                v.normal_(0.0, std, generator=g)
+        self.sync_bf16()
+
+
+def rope_tables(ids, axes_dims, theta=10000.0):
+    """FluxPosEmbed tables [S, head_dim] fp32 (angles in fp64), computed once per id set on the device."""
+    cos, sin = [], []
+    pos = ids.float()
+    for a, dim in enumerate(axes_dims):
+        fr = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64, device=ids.device) / dim))
+        ang = torch.outer(pos[:, a].double(), fr)
+        cos.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos, -1).contiguous(), torch.cat(sin, -1).contiguous()
+
+
+class _Work:
+    """Activation workspace for one (B, L, N) problem size, reused across calls."""
+
+    def __init__(self, cfg, B, L, N, device):
+        d, H, hd = cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
+        S = L + N
+        self.B, self.L, self.N, self.S = B, L, N, S
+        self.Sp = (S + 63) // 64 * 64
+        e = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=device)
+        self.X = e(B, S, d)
+        self.nrm = e(B * S, d)
+        self.qkv = e(B * S, 3 * d)
+        self.Q = e(B, H, S, hd)
+        self.K = e(B, H, S, hd)
+        self.Vt = torch.zeros(B, H, hd, self.Sp, dtype=BF16, device=device)   # padding must stay finite
+        self.O = e(B, S, d)
+        self.hid = e(B * S, 4 * d)
+        self.cat = e(B, S, 5 * d)
+        self.in16 = e(B * N, cfg.in_channels)
+        self.out = e(B, N, cfg.patch_size * cfg.patch_size * cfg.in_channels)
+        self.lse = e(B, H, S, dtype=F32)
+
+
+class FluxTransformer2DModel(torch.nn.Module):
+    """MI355X-native FLUX MMDiT.  `hipflux = FluxTransformer2DModel(FluxConfig(), device="cuda")`."""
+
+    def __init__(self, config: FluxConfig = None, device="cuda", **cfg_kwargs):
+        super().__init__()
+        self.cfg = config or FluxConfig(**cfg_kwargs)
+        self.config = self.cfg.to_dict()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise MgxError("FluxTransformer2DModel (mixgrpo_amd) runs on an MI355X only; there is no CPU path")
+        self.store = ParamStore(self.cfg, dev)
+        # one flat fp32 parameter (what optimizers / clip_grad_norm_ see); named views via state_dict()
+        self.flat_param = torch.nn.Parameter(self.store.w32, requires_grad=True)
+        self._work: Dict[Tuple[int, int, int], _Work] = {}
+        self._rope_cache = {}
+        self.recompute = True
+
+    # ------------------------------------------------------------------ parameters / checkpoints
+    def state_dict(self, *args, **kwargs):
+        return {k: self.store.view(self.store.w32, k) for k in self.store.index}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.store.index if k not in sd]
+        unexpected = [k for k in sd if k not in self.store.index]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in self.store.index:
+                    self.store.view(self.store.w32, k).copy_(v.to(F32))
+        self.store.sync_bf16()
+        return missing, unexpected
+
+    def init_synthetic(self, seed=0, std=0.02, bias_std=0.0):
+        self.store.init_synthetic(seed, std, bias_std)
+        return self
+
+    def W(self, name):
+        return self.store.view(self.store.w16, name)
+
+    def W32(self, name):
+        return self.store.view(self.store.w32, name)
+
+    def clip_grad_norm_(self, max_norm):
+        """Global L2 norm of the fp32 gradients, scaled in place like torch's clip_grad_norm_ (reference :606)."""
+        g = self.store.ensure_grad()
+        nsq = torch.zeros(1, dtype=F32, device=g.device)
+        ops.sqnorm(g, nsq)
+        total = nsq.sqrt()
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        g.mul_(coef)
+        return total.squeeze(0)
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, B, L, N):
+        key = (B, L, N)
+        w = self._work.get(key)
+        if w is None:
+            if len(self._work) >= 2:   # keep at most two problem sizes resident (rollout + replay)
+                self._work.pop(next(iter(self._work)))
+            w = _Work(self.cfg, B, L, N, self.store.device)
+            self._work[key] = w
+        return w
+
+    def _rope(self, txt_ids, img_ids):
+        key = (id(txt_ids), txt_ids._version, tuple(txt_ids.shape), id(img_ids), img_ids._version, tuple(img_ids.shape))
+        hit = self._rope_cache.get("k")
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        ids = torch.cat([txt_ids.float(), img_ids.float()], dim=0)
+        cos, sin = rope_tables(ids, self.cfg.axes_dims_rope)
+        self._rope_cache["k"] = (key, cos, sin, txt_ids, img_ids)   # keep the id tensors alive with the key
+        return cos, sin
+
+    def _temb(self, B, timestep, guidance, pooled, keep=None):
+        """temb = t_emb + g_emb + text_emb (bf16 after every op), st = silu(temb)."""
+        d = self.cfg.dim
+        dev = self.store.device
+        t = (timestep.to(BF16) * 1000).float().contiguous()          # `.to(hidden.dtype) * 1000` under autocast
+        gd = guidance.to(dev)
+        gd = (gd.to(BF16) * 1000).float()
+        gd = gd.expand(B).contiguous() if gd.numel() == 1 else gd.contiguous()
+
+        def mlp(name, x, K):
+            h1 = torch.empty(B, d, dtype=BF16, device=dev)
+            ops.skinny_linear(x, self.W(f"time_text_embed.{name}.linear_1.weight"),
+                              self.W(f"time_text_embed.{name}.linear_1.bias"), h1, d, K)
+            a1 = torch.empty_like(h1)
+            ops.ew(h1, None, a1, 0)
+            h2 = torch.empty_like(h1)
+            ops.skinny_linear(a1, self.W(f"time_text_embed.{name}.linear_2.weight"),
+                              self.W(f"time_text_embed.{name}.linear_2.bias"), h2, d, d)
+            if keep is not None:
+                keep[name] = (x, h1, a1)
+            return h2
+
+        te = torch.empty(B, 256, dtype=BF16, device=dev)
+        ops.sincos_embed(t, te)
+        temb = mlp("timestep_embedder", te, 256)
+        if self.cfg.guidance_embeds:
+            ge = torch.empty(B, 256, dtype=BF16, device=dev)
+            ops.sincos_embed(gd, ge)
+            gemb = mlp("guidance_embedder", ge, 256)
+            t2 = torch.empty_like(temb)
+            ops.ew(temb, gemb, t2, 2)
+            temb = t2
+        pe = mlp("text_embedder", pooled.to(BF16).contiguous(), self.cfg.pooled_projection_dim)
+        t3 = torch.empty_like(temb)
+        ops.ew(temb, pe, t3, 2)
+        st = torch.empty_like(t3)
+        ops.ew(t3, None, st, 0)
+        return t3, st
+
+    def _stream_rows(self, t, w, which, width):
+        """Row-batched view of the text ('txt') or image ('img') rows of a joint [B, S, width] buffer."""
+        if which == "txt":
+            return Rows(t, w.B * w.L, width, w.L, w.S * width)
+        return Rows(t[0, w.L:], w.B * w.N, width, w.N, w.S * width)
+
+    def _double_block(self, i, w, st, cos, sin, save=None):
+        cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
+        p = f"transformer_blocks.{i}"
+        B = w.B
+        dev = self.store.device
+        mods = {}
+        streams = (("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", w.N, w.L),
+                   ("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
+                    "to_add_out", "ff_context", w.L, 0))
+        row0 = {"txt": 0, "img": w.B * w.L}     # row offsets inside the per-stream scratch buffers
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            m = torch.empty(B, 6 * d, dtype=BF16, device=dev)
+            ops.skinny_linear(st, self.W(f"{p}.{norm}.linear.weight"), self.W(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
+            mods[name] = m
+            Xs = self._stream_rows(w.X, w, name, d)
+            M = B * rows
+            nrm = w.nrm[row0[name]:row0[name] + M]
+            qkv = w.qkv[row0[name]:row0[name] + M]
+            ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm, d)
+            ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
+                     self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv), 3 * d, d)
+            ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
+                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0)
+        ops.attn_fwd(w.Q, w.K, w.Vt, w.O, w.lse if save is not None else None, B, H, w.S, w.Sp, d, w.S * d,
+                     1.0 / math.sqrt(cfg.attention_head_dim))
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            m = mods[name]
+            M = B * rows
+            Xs = self._stream_rows(w.X, w, name, d)
+            Os = self._stream_rows(w.O, w, name, d)
+            nrm = w.nrm[row0[name]:row0[name] + M]
+            hid = w.hid[row0[name]:row0[name] + M]
+            aux1 = aux2 = hpre = None
+            if save is not None:
+                aux1 = save[f"{name}_y_attn"]
+                aux2 = save[f"{name}_y_ff"]
+                hpre = save[f"{name}_hid_pre"]
+            ops.gemm(Os, self.W(f"{p}.attn.{outn}.weight"), self.W(f"{p}.attn.{outn}.bias"), Xs, d, d,
+                     EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=6 * d, aux=aux1)
+            if save is not None:
+                save[f"{name}_x_mid"].copy_(w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
+            ops.ln_modulate(Xs, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
+            ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
+                     Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
+            ops.gemm(Rows.of(hid), self.W(f"{p}.{ffn}.net.2.weight"), self.W(f"{p}.{ffn}.net.2.bias"), Xs, d, 4 * d,
+                     EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
+        return mods
+
+    def _single_block(self, i, w, st, cos, sin, save=None):
+        cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
+        p = f"single_transformer_blocks.{i}"
+        B, S = w.B, w.S
+        M = B * S
+        m = torch.empty(B, 3 * d, dtype=BF16, device=self.store.device)
+        ops.skinny_linear(st, self.W(f"{p}.norm.linear.weight"), self.W(f"{p}.norm.linear.bias"), m, 3 * d, d)
+        Xa = Rows(w.X, M, d, S, S * d)
+        ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, w.nrm, d)
+        ops.gemm(Rows.of(w.nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
+                 self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(w.qkv), 3 * d, d)
+        cat2 = w.cat.view(M, 5 * d)
+        ops.gemm(Rows.of(w.nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
+                 Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
+                 aux=None if save is None else save["mlp_pre"], )
+        ops.qk_norm_rope(w.qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
+                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0)
+        ops.attn_fwd(w.Q, w.K, w.Vt, w.cat, w.lse if save is not None else None, B, H, S, w.Sp, 5 * d, S * 5 * d,
+                     1.0 / math.sqrt(cfg.attention_head_dim))
+        ops.gemm(Rows.of(cat2), self.W(f"{p}.proj_out.weight"), self.W(f"{p}.proj_out.bias"), Xa, d, 5 * d,
+                 EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=3 * d, aux=None if save is None else save["y"])
+        return m
+
+    def _embed(self, w, hidden_states, encoder_hidden_states):
+        d = self.cfg.dim
+        B, N, L = w.B, w.N, w.L
+        hs = hidden_states.detach()
+        if hs.dtype == BF16:
+            w.in16.copy_(hs.reshape(B * N, -1))
+        else:
+            ops.cast_bf16(hs.to(F32).contiguous().view(-1), w.in16.view(-1))
+        ops.gemm(Rows.of(w.in16), self.W("x_embedder.weight"), self.W("x_embedder.bias"),
+                 self._stream_rows(w.X, w, "img", d), d, self.cfg.in_channels)
+        ehs = encoder_hidden_states.detach().to(BF16).contiguous()
+        ops.gemm(Rows.of(ehs.view(B * L, -1)), self.W("context_embedder.weight"), self.W("context_embedder.bias"),
+                 self._stream_rows(w.X, w, "txt", d), d, self.cfg.joint_attention_dim)
+        return ehs
+
+    def _head(self, w, st):
+        d = self.cfg.dim
+        B, N = w.B, w.N
+        e = torch.empty(B, 2 * d, dtype=BF16, device=self.store.device)
+        ops.skinny_linear(st, self.W("norm_out.linear.weight"), self.W("norm_out.linear.bias"), e, 2 * d, d)
+        nrm = w.nrm[:B * N]
+        ops.ln_modulate(self._stream_rows(w.X, w, "img", d), e[:, d:2 * d], e[:, 0:d], 2 * d, nrm, d)   # scale first
+        cout = self.cfg.patch_size * self.cfg.patch_size * self.cfg.in_channels
+        out = torch.empty(B, N, cout, dtype=BF16, device=self.store.device)
+        ops.gemm(Rows.of(nrm), self.W("proj_out.weight"), self.W("proj_out.bias"), Rows.of(out.view(B * N, cout)), cout, d)
+        return out, e
+
+    def forward(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids, pooled_projections, img_ids,
+                joint_attention_kwargs=None, return_dict=False):
+        if torch.is_grad_enabled() and self.training and self.flat_param.requires_grad:
+            from .flux_backward import FluxFunction
+            out = FluxFunction.apply(self.flat_param, self, hidden_states, encoder_hidden_states, timestep, guidance,
+                                     txt_ids, pooled_projections, img_ids)
+            return (out,)
+        with torch.no_grad():
+            out = self._forward_nograd(hidden_states, encoder_hidden_states, timestep, guidance, txt_ids,
+                                       pooled_projections, img_ids)
+        return (out,)
+
+    def _forward_nograd(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids, pooled_projections,
+                        img_ids, collect=None):
+        B, N, _ = hidden_states.shape
+        L = encoder_hidden_states.shape[1]
+        w = self._workspace(B, L, N)
+        self._embed(w, hidden_states, encoder_hidden_states)
+        temb, st = self._temb(B, timestep.to(self.store.device), guidance, pooled_projections)
+        cos, sin = self._rope(txt_ids, img_ids)
+        if collect is not None:
+            collect.update(temb=temb.clone(), x_embed=w.X[:, L:].clone(), ctx_embed=w.X[:, :L].clone())
+        for i in range(self.cfg.num_layers):
+            self._double_block(i, w, st, cos, sin)
+            if collect is not None:
+                collect[f"double{i}_h"] = w.X[:, L:].clone()
+                collect[f"double{i}_c"] = w.X[:, :L].clone()
+        for i in range(self.cfg.num_single_layers):
+            self._single_block(i, w, st, cos, sin)
+            if collect is not None:
+                collect[f"single{i}_x"] = w.X.clone()
+        out, _ = self._head(w, st)
+        return out
+
+    # ------------------------------------------------------------------ checkpoint format (reference checkpoint.py:65-88)
+    def save_pretrained(self, save_dir):
+        from safetensors.torch import save_file
+        os.makedirs(save_dir, exist_ok=True)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(save_dir, "diffusion_pytorch_model.safetensors"))
+        cfg = dict(self.config)
+        cfg.pop("dtype", None)
+        with open(os.path.join(save_dir, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=4)
+
+    @classmethod
+    def from_pretrained(cls, path, device="cuda"):
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            raw = json.load(f)
+        keys = {f.name for f in FluxConfig.__dataclass_fields__.values()}
+        cfg = FluxConfig(**{k: (tuple(v) if k == "axes_dims_rope" else v) for k, v in raw.items() if k in keys})
+        m = cls(cfg, device=device)
+        m.load_state_dict(load_file(os.path.join(path, "diffusion_pytorch_model.safetensors")))
+        return m

@@ -30,7 +30,8 @@ class Rows:
 def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, aux=None, beta=0.0, ldw=None):
     """C = epi(A @ W[N,K]^T + bias).  `aux` shares C's row map."""
     assert A.M == C.M
-    check(lib().mgx_gemm_bf16(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), ptr(gate), ptr(aux), A.M, N, K, A.ld, A.rpb,
+    check(lib().mgx_gemm_bf16(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), None if gate is None else gate.data_ptr(),
+                              ptr(aux), A.M, N, K, A.ld, A.rpb,
                               A.bstride, K if ldw is None else ldw, C.ld, C.rpb, C.bstride, gate_ld, epi, beta, stream()))
 
 
@@ -54,3 +55,78 @@ def transpose(inp: Rows, N, out, ld_out, colsum_out=None, colsum_beta=1.0):
         part = scratch("colsum_partial", lib().mgx_transpose_partial_elems(inp.M, N), F32, out.device)
     check(lib().mgx_transpose_bf16(ptr(inp.t), ptr(out), ptr(part), ptr(colsum_out), colsum_beta, inp.M, N, inp.ld,
                                    inp.rpb, inp.bstride, ld_out, stream()))
+
+
+def ln_modulate(x: Rows, shift, scale, mod_ld, y, D, stats=None):
+    """y[M, D] = bf16(LN(x) * bf16(1+scale[b]) + shift[b]); shift/scale are views at their chunk of mod [B, mod_ld]."""
+    check(lib().mgx_ln_modulate_fwd(ptr(x.t), x.ld, x.rpb, x.bstride, shift.data_ptr(), scale.data_ptr(), mod_ld, ptr(y),
+                                    D, ptr(stats), x.M, D, stream()))
+
+
+def ln_modulate_bwd(dy, x: Rows, scale, mod_ld, dx: Rows, accumulate, dshift, dscale, D):
+    ws = scratch("ln_bwd", lib().mgx_ln_modulate_bwd_workspace(x.M, min(x.rpb, x.M), D), F32, dy.device)
+    check(lib().mgx_ln_modulate_bwd(ptr(dy), D, ptr(x.t), x.ld, min(x.rpb, x.M), x.bstride, scale.data_ptr(), mod_ld,
+                                    ptr(dx.t), dx.ld, min(dx.rpb, dx.M), dx.bstride, int(accumulate), dshift.data_ptr(),
+                                    dscale.data_ptr(), ptr(ws), x.M, D, stream()))
+
+
+def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s0):
+    check(lib().mgx_qk_norm_rope_fwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K), ptr(Vt),
+                                     B, H, S, Sp, rows_per_batch, s0, stream()))
+
+
+def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dVt, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0):
+    ws = scratch("qk_bwd", lib().mgx_qk_norm_rope_bwd_workspace(B, H, rows_per_batch), F32, qkv.device)
+    check(lib().mgx_qk_norm_rope_bwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
+                                     ptr(dVt), ptr(dqkv), ptr(gwq), ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0,
+                                     stream()))
+
+
+def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):
+    check(lib().mgx_attn_fwd(ptr(Q), ptr(K), ptr(Vt), O_ptr_tensor.data_ptr(), ptr(lse), B, H, S, Sp, ldo, o_bstride,
+                             scale, stream()))
+
+
+def skinny_linear(x, W, bias, out, N, K):
+    """out[b] = bf16(x[b] @ W^T + bias) for <= 16 rows per call (more rows are chunked)."""
+    Bn = x.shape[0]
+    for b0 in range(0, Bn, 16):
+        nb = min(16, Bn - b0)
+        check(lib().mgx_skinny_linear(x[b0:].data_ptr(), x.stride(0), ptr(W), K, ptr(bias), out[b0:].data_ptr(),
+                                      out.stride(0), nb, N, K, stream()))
+
+
+def skinny_wgrad(dout, x, dW, dbias, N, K):
+    Bn = x.shape[0]
+    for b0 in range(0, Bn, 16):
+        nb = min(16, Bn - b0)
+        check(lib().mgx_skinny_wgrad(dout[b0:].data_ptr(), dout.stride(0), x[b0:].data_ptr(), x.stride(0), ptr(dW), K,
+                                     ptr(dbias), nb, N, K, stream()))
+
+
+def ew(a, b, y, op):
+    check(lib().mgx_ew_bf16(ptr(a), ptr(b), ptr(y), a.numel(), op, stream()))
+
+
+def sincos_embed(t, out):
+    check(lib().mgx_sincos_embed(ptr(t), ptr(out), t.numel(), stream()))
+
+
+def cast_bf16(x, y):
+    check(lib().mgx_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()))
+
+
+def gate_bwd(dout: Rows, y, gate, gate_ld, dy, dgate, batches, rows_per_batch, D):
+    ws = scratch("gate_bwd", lib().mgx_gate_bwd_workspace(batches, rows_per_batch, D), F32, y.device)
+    check(lib().mgx_gate_bwd(ptr(dout.t), dout.ld, dout.bstride, ptr(y), D, gate.data_ptr(), gate_ld, ptr(dy), D,
+                             dgate.data_ptr(), ptr(ws), batches, rows_per_batch, D, stream()))
+
+
+def sqnorm(g, out, beta=0.0):
+    ws = scratch("sqnorm", lib().mgx_sqnorm_workspace(), torch.float64, g.device)
+    check(lib().mgx_sqnorm_f32(ptr(g), g.numel(), ptr(ws), ptr(out), beta, stream()))
+
+
+def adamw_step(w, w16, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, grad_scale=1.0):
+    check(lib().mgx_adamw_step(ptr(w), ptr(w16), ptr(g), ptr(m), ptr(v), w.numel(), lr, beta1, beta2, eps, wd, step,
+                               ptr(gnorm_sq), max_norm, grad_scale, stream()))
