@@ -139,9 +139,9 @@ enum { MGX_EPI_BIAS = 0, MGX_EPI_BIAS_GELU = 1, MGX_EPI_BIAS_GATE_RES = 2, MGX_E
  *   MGX_EPI_BIAS_GATE_RES C = bf16(C + bf16(gate[m/c_rpb, n] * bf16(acc + bias)));  aux (optional) <- pre-gate
  *   MGX_EPI_F32_ACC       C(fp32) = beta * C + acc                  (weight gradients)
  *   MGX_EPI_DGELU         C = bf16(bf16(acc) * gelu_tanh'(aux))     (input gradient through GELU)
- * K % 64 == 0, N % 4 == 0; M, N tails are masked. */
+ * aux is a plain [M, ldaux] matrix.  K % 64 == 0, N % 4 == 0; M, N tails are masked. */
 int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
-                  uint16_t* aux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                  uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                   long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream);
 
 /* out[N, ld_out] = in[M, N]^T (bf16; columns M..ld_out-1 are zero-filled) and, optionally, fp32 column sums
@@ -166,12 +166,14 @@ int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t* x, long l
 /* Per-head RMSNorm(eps 1e-6, fp32 weight[128]) on q,k + interleaved-pair RoPE (fp32 cos/sin [S,128]) + head
  * split: qkv [B*rows_per_batch, 3*H*128] -> Q,K [B,H,S,128] (rounded once to bf16), Vt [B,H,128,Sp], written
  * at sequence positions s0 .. s0+rows_per_batch-1 of the joint sequence (diffusers FluxAttnProcessor2_0). */
+/* V, Qt, Kt (all or none): extra layouts the attention backward consumes -- V row-major [B,H,S,128] and
+ * Q^T, K^T [B,H,128,Sp] (padding must be finite: allocate zeroed). */
 int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                         const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int H, int S, int Sp,
-                         int rows_per_batch, int s0, void* stream);
+                         const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
+                         uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream);
 long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch);
 int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                         const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dVt, uint16_t* dqkv,
+                         const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dqkv,
                          float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp, int rows_per_batch, int s0,
                          void* stream);
 
@@ -180,6 +182,14 @@ int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const fl
  * lse [B,H,S] (optional, natural log) for the backward pass. */
 int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H, int S,
                  int Sp, long ldo, long o_bstride, float scale, void* stream);
+
+/* Backward of mgx_attn_fwd (P recomputed from lse): dQ, dK, dV [B,H,S,128].  Inputs Q,K,V row-major, Qt,Kt
+ * [B,H,128,Sp] (mgx_qk_norm_rope_fwd extras), O and dO [B,S,ldo] at column h*128.  delta [B,H,S] fp32 and dOt
+ * [B,H,128,Sp] bf16 are caller-provided scratch filled by the internal prep kernel. */
+int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* V, const uint16_t* Qt, const uint16_t* Kt,
+                 const uint16_t* O, const uint16_t* dO, const float* lse, float* delta, uint16_t* dOt, uint16_t* dQ,
+                 uint16_t* dK, uint16_t* dV, int B, int H, int S, int Sp, long ldo, long o_bstride, float scale,
+                 void* stream);
 
 /* out[b, :] = bf16(x[b, :] @ W[N,K]^T + bias), 1 <= Bn <= 16 rows (temb MLPs, AdaLN modulation linears) */
 int mgx_skinny_linear(const uint16_t* x, long ldx, const uint16_t* W, long ldw, const uint16_t* bias, uint16_t* out,

@@ -53,16 +53,17 @@ SIGNATURES = {
     "mgx_group_advantage": (_I, [_P, _P, _I, _I, _F, _F, _I, _P]),
     "mgx_global_advantage": (_I, [_P, _P, _P, _I, _I, _P]),
     "mgx_grpo_loss": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
-    "mgx_gemm_bf16": (_I, [_P] * 6 + [_I, _I, _I] + [_L] * 8 + [_I, _F, _P]),
+    "mgx_gemm_bf16": (_I, [_P] * 6 + [_L, _I, _I, _I] + [_L] * 8 + [_I, _F, _P]),
     "mgx_transpose_partial_elems": (_L, [_I, _I]),
     "mgx_transpose_bf16": (_I, [_P, _P, _P, _P, _F, _I, _I, _L, _L, _L, _L, _P]),
     "mgx_ln_modulate_fwd": (_I, [_P, _L, _L, _L, _P, _P, _L, _P, _L, _P, _L, _I, _P]),
     "mgx_ln_modulate_bwd_workspace": (_L, [_L, _L, _I]),
     "mgx_ln_modulate_bwd": (_I, [_P, _L, _P, _L, _L, _L, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P, _L, _I, _P]),
-    "mgx_qk_norm_rope_fwd": (_I, [_P, _L] + [_P] * 7 + [_I] * 6 + [_P]),
+    "mgx_qk_norm_rope_fwd": (_I, [_P, _L] + [_P] * 10 + [_I] * 6 + [_P]),
     "mgx_qk_norm_rope_bwd_workspace": (_L, [_I, _I, _I]),
     "mgx_qk_norm_rope_bwd": (_I, [_P, _L] + [_P] * 11 + [_I] * 6 + [_P]),
     "mgx_attn_fwd": (_I, [_P] * 5 + [_I] * 4 + [_L, _L, _F, _P]),
+    "mgx_attn_bwd": (_I, [_P] * 13 + [_I] * 4 + [_L, _L, _F, _P]),
     "mgx_skinny_linear": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P]),
     "mgx_skinny_wgrad": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "mgx_ew_bf16": (_I, [_P, _P, _P, _L, _I, _P]),

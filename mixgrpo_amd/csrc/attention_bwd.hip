@@ -1,0 +1,384 @@
+// Joint attention backward (non-causal, head_dim 128) for the FLUX MMDiT replay pass.
+//
+// Replaces the autograd of F.scaled_dot_product_attention (flash-attention backward in the reference's stack).
+// P is recomputed from Q, K and the forward's LSE.  Two kernels, no atomics, bitwise reproducible:
+//   * attn_bwd_dkv : one wave owns 32 keys (K, V fragments in registers), the workgroup (8 waves = 256 keys)
+//                    sweeps 32-query tiles;  S = Q K^T and dP = dO V^T with the KEY on the MFMA lane, so their
+//                    accumulators are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS.
+//   * attn_bwd_dq  : one wave owns 32 queries (Q, dO fragments in registers), the workgroup (256 queries) sweeps
+//                    64-key tiles;  S^T = K Q^T, dP^T = V dO^T with the QUERY on the lane, dQ^T += K^T dS^T.
+// Operands that are consumed "k-strided" by the second product of each pair are provided pre-transposed in
+// global memory ([B,H,128,Sp]: Qt, Kt by qk_norm_rope, dOt by attn_bwd_prep), so every LDS fragment read is a
+// plain conflict-free ds_read (XOR-swizzled images), cf. the forward kernel.
+#include "../../include/mixgrpo_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+// row-major [rows][128] bf16 image, 16-byte chunk swizzle
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+// transposed [128 d][64 cols] image (128-byte rows), 8-byte chunk swizzle
+__device__ __forceinline__ int t64_off(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
+// transposed [128 d][32 cols] image (64-byte rows), 8-byte chunk swizzle
+__device__ __forceinline__ int t32_off(int d, int c8) { return d * 64 + ((c8 ^ ((d >> 2) & 7)) << 3); }
+
+__device__ __forceinline__ void xcd_remap(int& bid, int nwg) {
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------ prep
+// delta[b,h,s] = sum_d dO[b,s,h*128+d] * O[b,s,h*128+d];  dOt[b,h,d,s] = dO[b,s,h*128+d]
+__global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_raw* __restrict__ O, const bf16_raw* __restrict__ dO,
+                                                            long ldo, long o_bstride, float* __restrict__ delta,
+                                                            bf16_raw* __restrict__ dOt, int H, int S, int Sp) {
+  __shared__ bf16_raw tile[64][130];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hh = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * 64;
+  for (int i = 0; i < 16; ++i) {
+    const int tl = w * 16 + i, s = t0 + tl;
+    uint32_t ud = 0;
+    float acc = 0.f;
+    if (s < S) {
+      const long off = (long)b * o_bstride + (long)s * ldo + hh * HD + 2 * lane;
+      ud = *reinterpret_cast<const uint32_t*>(dO + off);
+      const uint32_t uo = *reinterpret_cast<const uint32_t*>(O + off);
+      acc = bf2f(ud & 0xffff) * bf2f(uo & 0xffff) + bf2f(ud >> 16) * bf2f(uo >> 16);
+    }
+    *reinterpret_cast<uint32_t*>(&tile[tl][2 * lane]) = ud;
+    acc = wave_sum(acc);
+    if (lane == 0 && s < S) delta[((long)b * H + hh) * S + s] = acc;
+  }
+  __syncthreads();
+  for (int id = threadIdx.x; id < 128 * 8; id += 256) {
+    const int d = id >> 3, c = id & 7;
+    bf16_raw* dst = dOt + (((long)b * H + hh) * HD + d) * Sp + t0 + c * 8;
+    if (t0 + c * 8 < Sp) {
+      uint4 u;
+      u.x = (uint32_t)tile[c * 8 + 0][d] | ((uint32_t)tile[c * 8 + 1][d] << 16);
+      u.y = (uint32_t)tile[c * 8 + 2][d] | ((uint32_t)tile[c * 8 + 3][d] << 16);
+      u.z = (uint32_t)tile[c * 8 + 4][d] | ((uint32_t)tile[c * 8 + 5][d] << 16);
+      u.w = (uint32_t)tile[c * 8 + 6][d] | ((uint32_t)tile[c * 8 + 7][d] << 16);
+      *reinterpret_cast<uint4*>(dst) = u;   // rows beyond S hold zeros (ud = 0)
+    }
+  }
+}
+
+struct BwdArgs {
+  const bf16_raw* Q;    // [B,H,S,128]
+  const bf16_raw* K;    // [B,H,S,128]
+  const bf16_raw* V;    // [B,H,S,128]
+  const bf16_raw* Qt;   // [B,H,128,Sp]
+  const bf16_raw* Kt;   // [B,H,128,Sp]
+  const bf16_raw* dO;   // [B,S,ldo] at column h*128
+  const bf16_raw* dOt;  // [B,H,128,Sp]
+  const float* lse;     // [B,H,S]
+  const float* delta;   // [B,H,S]
+  bf16_raw* dQ;         // [B,H,S,128]
+  bf16_raw* dK;
+  bf16_raw* dV;
+  int B, H, S, Sp;
+  long ldo, o_bstride;
+  float scale, scale_log2e;
+};
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+// LDS per q-tile (32 queries): Q rm [32][128] 8K | dO rm 8K | Qt t32 [128][32] 8K | dOt t32 8K | lse 128 B | delta 128 B
+constexpr int DKV_STAGE = 4 * 8192 + 256;
+__global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkb = (g.S + 255) / 256;
+  int bid = blockIdx.x;
+  xcd_remap(bid, nkb * g.H * g.B);
+  const int kt = bid % nkb, bh = bid / nkb;
+  const int b = bh / g.H, hh = bh - b * g.H;
+  const long bhS = (long)bh * g.S;
+  const bf16_raw* Qp = g.Q + bhS * HD;
+  const bf16_raw* Qtp = g.Qt + (long)bh * HD * g.Sp;
+  const bf16_raw* dOtp = g.dOt + (long)bh * HD * g.Sp;
+  const bf16_raw* dOp = g.dO + (long)b * g.o_bstride + hh * HD;
+
+  // own keys: K and V fragments as B operands: B[k = d][col = key]  -> K[key0 + r][16ks + 8h + j]
+  const int key0 = kt * 256 + wid * 32;
+  int krow = key0 + r;
+  const bool key_valid = krow < g.S;
+  if (krow >= g.S) krow = g.S - 1;
+  s16x8 kf[8], vf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    kf[ks] = *reinterpret_cast<const s16x8*>(g.K + (bhS + krow) * HD + ks * 16 + h * 8);
+    vf[ks] = *reinterpret_cast<const s16x8*>(g.V + (bhS + krow) * HD + ks * 16 + h * 8);
+  }
+  f32x16 dv[4], dk[4];   // dV^T, dK^T tiles: rows d = 32*dt + ..., column = key r
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dv[dt][i] = dk[dt][i] = 0.f;
+
+  // staging roles: 512 threads; Q rm: 512 chunks (row = id>>4, chunk = id&15); dO rm same; Qt/dOt t32: 512 16-B
+  // chunks each (d = id>>2, c16 = id&3 -> two 8-byte chunks)
+  const int s_row = tid >> 4, s_chunk = tid & 15;
+  const int s_d = tid >> 2, s_c16 = tid & 3;
+  uint4 rq, rdo, rqt, rdot;
+  float rl = 0.f;
+  const int nqt = (g.S + 31) / 32;
+#define DKV_LOAD(t)                                                                                   \
+  do {                                                                                                \
+    const int q_base = (t) * 32;                                                                      \
+    int qr = q_base + s_row;                                                                          \
+    if (qr >= g.S) qr = g.S - 1;                                                                      \
+    rq = *reinterpret_cast<const uint4*>(Qp + (long)qr * HD + s_chunk * 8);                           \
+    rdo = *reinterpret_cast<const uint4*>(dOp + (long)qr * g.ldo + s_chunk * 8);                      \
+    rqt = *reinterpret_cast<const uint4*>(Qtp + (long)s_d * g.Sp + q_base + s_c16 * 8);               \
+    rdot = *reinterpret_cast<const uint4*>(dOtp + (long)s_d * g.Sp + q_base + s_c16 * 8);             \
+    if (tid < 64) {                                                                                   \
+      int qq = q_base + (tid & 31);                                                                   \
+      const bool ok = qq < g.S;                                                                       \
+      if (!ok) qq = g.S - 1;                                                                          \
+      rl = (tid < 32) ? (ok ? g.lse[bhS + qq] * 1.4426950408889634f : INFINITY) : g.delta[bhS + qq];  \
+    }                                                                                                 \
+  } while (0)
+#define DKV_STORE(buf)                                                                                \
+  do {                                                                                                \
+    char* base = smem + (buf) * DKV_STAGE;                                                            \
+    *reinterpret_cast<uint4*>(base + rm_off(s_row, s_chunk)) = rq;                                    \
+    *reinterpret_cast<uint4*>(base + 8192 + rm_off(s_row, s_chunk)) = rdo;                            \
+    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, 2 * s_c16)) = make_uint2(rqt.x, rqt.y);     \
+    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, 2 * s_c16 + 1)) = make_uint2(rqt.z, rqt.w); \
+    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, 2 * s_c16)) = make_uint2(rdot.x, rdot.y);   \
+    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, 2 * s_c16 + 1)) = make_uint2(rdot.z, rdot.w); \
+    if (tid < 64) reinterpret_cast<float*>(base + 32768)[tid] = rl;                                   \
+  } while (0)
+
+  DKV_LOAD(0);
+  DKV_STORE(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nqt; ++t) {
+    if (t + 1 < nqt) DKV_LOAD(t + 1);
+    const char* base = smem + cur * DKV_STAGE;
+    const float* lse2 = reinterpret_cast<const float*>(base + 32768);
+    const float* dlt = lse2 + 32;
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const s16x8 qa = *reinterpret_cast<const s16x8*>(base + rm_off(r, ks * 2 + h));
+      const s16x8 da = *reinterpret_cast<const s16x8*>(base + 8192 + rm_off(r, ks * 2 + h));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+    }
+    // P[q][key] and dS[q][key]; q = (i&3) + 8*(i>>2) + 4h (rows), key = this lane's column
+    uint32_t pb[8], dsb[8];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const int qa = (i & 3) + 8 * (i >> 2) + 4 * h, qb = qa + 1;
+      float p0 = exp2f(s[i] * g.scale_log2e - lse2[qa]);       // rows beyond S carry lse = +inf -> P = 0
+      float p1 = exp2f(s[i + 1] * g.scale_log2e - lse2[qb]);
+      if (!key_valid) p0 = p1 = 0.f;
+      const float d0 = p0 * (dp[i] - dlt[qa]) * g.scale;
+      const float d1 = p1 * (dp[i + 1] - dlt[qb]) * g.scale;
+      pb[i >> 1] = pack_bf16(p0, p1);
+      dsb[i >> 1] = pack_bf16(d0, d1);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const s16x8 pf = __builtin_bit_cast(s16x8, make_uint4(pb[4 * s2], pb[4 * s2 + 1], pb[4 * s2 + 2], pb[4 * s2 + 3]));
+      const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
+      const int c8 = (16 * s2 + 4 * h) >> 2;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 32 + r;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(base + 24576 + t32_off(d, c8));
+        const uint2 a1 = *reinterpret_cast<const uint2*>(base + 24576 + t32_off(d, c8 + 2));
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)), pf,
+                                                         dv[dt], 0, 0, 0);
+        const uint2 b0 = *reinterpret_cast<const uint2*>(base + 16384 + t32_off(d, c8));
+        const uint2 b1 = *reinterpret_cast<const uint2*>(base + 16384 + t32_off(d, c8 + 2));
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(b0.x, b0.y, b1.x, b1.y)), df,
+                                                         dk[dt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nqt) DKV_STORE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int key = key0 + r;
+  if (key < g.S) {
+    bf16_raw* dkp = g.dK + (bhS + key) * HD;
+    bf16_raw* dvp = g.dV + (bhS + key) * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int d = dt * 32 + 8 * i4 + 4 * h;
+        *reinterpret_cast<uint2*>(dkp + d) = make_uint2(pack_bf16(dk[dt][4 * i4], dk[dt][4 * i4 + 1]),
+                                                        pack_bf16(dk[dt][4 * i4 + 2], dk[dt][4 * i4 + 3]));
+        *reinterpret_cast<uint2*>(dvp + d) = make_uint2(pack_bf16(dv[dt][4 * i4], dv[dt][4 * i4 + 1]),
+                                                        pack_bf16(dv[dt][4 * i4 + 2], dv[dt][4 * i4 + 3]));
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+// LDS per key tile (64 keys): K rm [64][128] 16K | V rm 16K | Kt t64 [128][64] 16K
+constexpr int DQ_STAGE = 3 * 16384;
+__global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nq = (g.S + 255) / 256;
+  int bid = blockIdx.x;
+  xcd_remap(bid, nq * g.H * g.B);
+  const int qt = bid % nq, bh = bid / nq;
+  const int b = bh / g.H, hh = bh - b * g.H;
+  const long bhS = (long)bh * g.S;
+  const bf16_raw* Kp = g.K + bhS * HD;
+  const bf16_raw* Vp = g.V + bhS * HD;
+  const bf16_raw* Ktp = g.Kt + (long)bh * HD * g.Sp;
+
+  const int q0 = qt * 256 + wid * 32;
+  int qrow = q0 + r;
+  const bool q_valid = qrow < g.S;
+  if (qrow >= g.S) qrow = g.S - 1;
+  s16x8 qf[8], dof[8];
+  const bf16_raw* dOp = g.dO + (long)b * g.o_bstride + (long)qrow * g.ldo + hh * HD;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    qf[ks] = *reinterpret_cast<const s16x8*>(g.Q + (bhS + qrow) * HD + ks * 16 + h * 8);
+    dof[ks] = *reinterpret_cast<const s16x8*>(dOp + ks * 16 + h * 8);
+  }
+  const float lse2 = g.lse[bhS + qrow] * 1.4426950408889634f;
+  const float dlt = g.delta[bhS + qrow];
+  f32x16 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
+
+  const int kc_key0 = tid >> 4, kc_chunk = tid & 15;
+  const int vc_d0 = tid >> 3, vc_chunk = tid & 7;
+  uint4 sk0, sk1, sv0, sv1, st0, st1;
+  const int ntiles = (g.S + 63) / 64;
+#define DQ_LOAD(t)                                                                                  \
+  do {                                                                                              \
+    const int key_base = (t) * 64;                                                                  \
+    int ka = key_base + kc_key0, kb_ = key_base + kc_key0 + 32;                                     \
+    if (ka >= g.S) ka = g.S - 1;                                                                    \
+    if (kb_ >= g.S) kb_ = g.S - 1;                                                                  \
+    sk0 = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                       \
+    sk1 = *reinterpret_cast<const uint4*>(Kp + (long)kb_ * HD + kc_chunk * 8);                      \
+    sv0 = *reinterpret_cast<const uint4*>(Vp + (long)ka * HD + kc_chunk * 8);                       \
+    sv1 = *reinterpret_cast<const uint4*>(Vp + (long)kb_ * HD + kc_chunk * 8);                      \
+    st0 = *reinterpret_cast<const uint4*>(Ktp + (long)vc_d0 * g.Sp + key_base + vc_chunk * 8);       \
+    st1 = *reinterpret_cast<const uint4*>(Ktp + (long)(vc_d0 + 64) * g.Sp + key_base + vc_chunk * 8); \
+  } while (0)
+#define DQ_STORE(buf)                                                                               \
+  do {                                                                                              \
+    char* base = smem + (buf) * DQ_STAGE;                                                           \
+    *reinterpret_cast<uint4*>(base + rm_off(kc_key0, kc_chunk)) = sk0;                              \
+    *reinterpret_cast<uint4*>(base + rm_off(kc_key0 + 32, kc_chunk)) = sk1;                         \
+    *reinterpret_cast<uint4*>(base + 16384 + rm_off(kc_key0, kc_chunk)) = sv0;                      \
+    *reinterpret_cast<uint4*>(base + 16384 + rm_off(kc_key0 + 32, kc_chunk)) = sv1;                 \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, 2 * vc_chunk)) = make_uint2(st0.x, st0.y); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, 2 * vc_chunk + 1)) = make_uint2(st0.z, st0.w); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, 2 * vc_chunk)) = make_uint2(st1.x, st1.y); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, 2 * vc_chunk + 1)) = make_uint2(st1.z, st1.w); \
+  } while (0)
+
+  DQ_LOAD(0);
+  DQ_STORE(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) DQ_LOAD(t + 1);
+    const char* base = smem + cur * DQ_STAGE;
+    const int key_base = t * 64;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const s16x8 ka = *reinterpret_cast<const s16x8*>(base + rm_off(kb * 32 + r, ks * 2 + h));
+        const s16x8 va = *reinterpret_cast<const s16x8*>(base + 16384 + rm_off(kb * 32 + r, ks * 2 + h));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dp, 0, 0, 0);
+      }
+      uint32_t dsb[8];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const int k0 = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        float p0 = exp2f(s[i] * g.scale_log2e - lse2);
+        float p1 = exp2f(s[i + 1] * g.scale_log2e - lse2);
+        if (k0 >= g.S) p0 = 0.f;
+        if (k0 + 1 >= g.S) p1 = 0.f;
+        dsb[i >> 1] = pack_bf16(p0 * (dp[i] - dlt) * g.scale, p1 * (dp[i + 1] - dlt) * g.scale);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
+        const int c8 = (kb * 32 + 16 * s2 + 4 * h) >> 2;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int d = dt * 32 + r;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(base + 32768 + t64_off(d, c8));
+          const uint2 a1 = *reinterpret_cast<const uint2*>(base + 32768 + t64_off(d, c8 + 2));
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)),
+                                                           df, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntiles) DQ_STORE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (q_valid) {
+    bf16_raw* dqp = g.dQ + (bhS + q0 + r) * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int d = dt * 32 + 8 * i4 + 4 * h;
+        *reinterpret_cast<uint2*>(dqp + d) = make_uint2(pack_bf16(dq[dt][4 * i4], dq[dt][4 * i4 + 1]),
+                                                        pack_bf16(dq[dt][4 * i4 + 2], dq[dt][4 * i4 + 3]));
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* V, const uint16_t* Qt, const uint16_t* Kt,
+                            const uint16_t* O, const uint16_t* dO, const float* lse, float* delta, uint16_t* dOt,
+                            uint16_t* dQ, uint16_t* dK, uint16_t* dV, int B, int H, int S, int Sp, long ldo, long o_bstride,
+                            float scale, void* stream) {
+  MGX_REQUIRE(Q && K && V && Qt && Kt && O && dO && lse && delta && dOt && dQ && dK && dV, "null operand");
+  MGX_REQUIRE(B > 0 && H > 0 && S > 0 && Sp >= S && Sp % 64 == 0, "bad sizes");
+  MGX_REQUIRE(ldo % 8 == 0 && o_bstride % 8 == 0, "dO rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  attn_bwd_prep_kernel<<<dim3(Sp / 64, H, B), 256, 0, st>>>(O, dO, ldo, o_bstride, delta, dOt, H, S, Sp);
+  BwdArgs g;
+  g.Q = Q; g.K = K; g.V = V; g.Qt = Qt; g.Kt = Kt; g.dO = dO; g.dOt = dOt; g.lse = lse; g.delta = delta;
+  g.dQ = dQ; g.dK = dK; g.dV = dV; g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
+  g.scale = scale; g.scale_log2e = scale * 1.4426950408889634f;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DQ_STAGE);
+    attr = true;
+  }
+  const int nb = cdiv(S, 256) * H * B;
+  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE, st>>>(g);
+  attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

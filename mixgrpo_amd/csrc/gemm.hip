@@ -38,7 +38,8 @@ struct GemmArgs {
   const bf16_raw* bias;   // [N] or null
   void* C;                // bf16 (or fp32 for EPI_F32_ACC)
   const bf16_raw* gate;   // [batches, gate_ld] (EPI_BIAS_GATE_RES): gate[b*gate_ld + n]
-  bf16_raw* aux;          // optional second output / input, same row map as C
+  bf16_raw* aux;          // optional second output / input: plain matrix, row m at aux + m*ldaux
+  long ldaux;
   long gate_ld;
   int M, N, K;
   RowMap a, c;
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
           uint2 pre;
           pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
           pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(g.aux + crow + n) = pre;
+          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
           uint2 pre;
           pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
           pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(g.aux + crow + n) = pre;
+          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
         }
         const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
         const uint2 rr = *reinterpret_cast<const uint2*>(cp);
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
         v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
       } else if (EPI == EPI_BIAS_MULAUX) {
         // dgrad through GELU: C = (A@W^T) * gelu'(aux)   (aux = saved pre-activation)
-        const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + crow + n);
+        const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + n);
         v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
         v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
       }
@@ -280,7 +281,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
-                             uint16_t* aux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                             uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                              long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream) {
   MGX_REQUIRE(A && W && C, "null operand");
   MGX_REQUIRE(M > 0 && N > 0 && K > 0, "empty GEMM");
@@ -288,10 +289,11 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   MGX_REQUIRE(N % 4 == 0, "N must be a multiple of 4");
   MGX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "leading dimensions must keep 16-byte row alignment");
   MGX_REQUIRE(a_rpb > 0 && c_rpb > 0, "rows-per-batch must be positive");
+  MGX_REQUIRE(!aux || ldaux % 4 == 0, "aux leading dimension must keep 8-byte alignment");
   MGX_REQUIRE(a_bstride % 8 == 0 && c_bstride % 4 == 0, "batch strides must keep alignment");
   MGX_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 8 == 0), "operands must be 16-byte aligned");
   GemmArgs g;
-  g.A = A; g.W = W; g.bias = bias; g.C = C; g.gate = gate; g.aux = aux; g.gate_ld = gate_ld;
+  g.A = A; g.W = W; g.bias = bias; g.C = C; g.gate = gate; g.aux = aux; g.ldaux = ldaux; g.gate_ld = gate_ld;
   g.M = M; g.N = N; g.K = K;
   g.a = RowMap{lda, a_rpb, a_bstride};
   g.c = RowMap{ldc, c_rpb, c_bstride};

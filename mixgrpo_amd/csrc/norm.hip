@@ -212,13 +212,19 @@ struct QkArgs {
   bf16_raw* Q;
   bf16_raw* K;
   bf16_raw* Vt;
+  bf16_raw* V;    // optional extras for the backward pass: V row-major [B,H,S,128], Qt/Kt [B,H,128,Sp]
+  bf16_raw* Qt;
+  bf16_raw* Kt;
   int H, S, Sp;
   int rows_per_batch;  // tokens of this stream per sample
   int s0;              // position of the stream's first token in the joint sequence
 };
 
+template <bool EMIT_T>
 __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
   __shared__ bf16_raw vt[64][130];
+  __shared__ bf16_raw qts[EMIT_T ? 64 : 1][130];
+  __shared__ bf16_raw kts[EMIT_T ? 64 : 1][130];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int hh = blockIdx.y, b = blockIdx.z;
   const int t0 = blockIdx.x * 64;
@@ -244,36 +250,46 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       const float x0 = bf2f(uq & 0xffff), x1 = bf2f(uq >> 16);
       const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
       const float y0 = x0 * r * wq0, y1 = x1 * r * wq1;
-      *reinterpret_cast<uint32_t*>(a.Q + o) = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+      const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+      *reinterpret_cast<uint32_t*>(a.Q + o) = pk;
+      if (EMIT_T) *reinterpret_cast<uint32_t*>(&qts[tl][2 * lane]) = pk;
     }
     {
       const float x0 = bf2f(uk & 0xffff), x1 = bf2f(uk >> 16);
       const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
       const float y0 = x0 * r * wk0, y1 = x1 * r * wk1;
-      *reinterpret_cast<uint32_t*>(a.K + o) = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+      const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+      *reinterpret_cast<uint32_t*>(a.K + o) = pk;
+      if (EMIT_T) *reinterpret_cast<uint32_t*>(&kts[tl][2 * lane]) = pk;
     }
+    if (EMIT_T) *reinterpret_cast<uint32_t*>(a.V + o) = uv;
   }
   __syncthreads();
-  // transposed V: Vt[b, h, d, s0 + t0 + 0..63] <- vt[t][d]; thread -> (d = id>>2.., 16 tokens chunk)
+  // transposed tiles: Xt[b, h, d, s0 + t0 + 0..63] <- tile[t][d]
   const int ntok = min(64, a.rows_per_batch - t0);
-  for (int id = threadIdx.x; id < 128 * 8; id += 256) {
-    const int d = id >> 3, c = id & 7;   // 8 tokens per 16-byte chunk
-    bf16_raw* dst = a.Vt + (((long)b * a.H + hh) * HD + d) * a.Sp + a.s0 + t0 + c * 8;
-    if (c * 8 + 8 <= ntok && (((a.s0 + t0) & 7) == 0)) {
-      uint4 u;
-      u.x = (uint32_t)vt[c * 8 + 0][d] | ((uint32_t)vt[c * 8 + 1][d] << 16);
-      u.y = (uint32_t)vt[c * 8 + 2][d] | ((uint32_t)vt[c * 8 + 3][d] << 16);
-      u.z = (uint32_t)vt[c * 8 + 4][d] | ((uint32_t)vt[c * 8 + 5][d] << 16);
-      u.w = (uint32_t)vt[c * 8 + 6][d] | ((uint32_t)vt[c * 8 + 7][d] << 16);
-      *reinterpret_cast<uint4*>(dst) = u;
-    } else {
-      for (int j = 0; j < 8; ++j)
-        if (c * 8 + j < ntok) dst[j] = vt[c * 8 + j][d];
+  const int nmat = EMIT_T ? 3 : 1;
+  for (int mat = 0; mat < nmat; ++mat) {
+    bf16_raw (*tile)[130] = mat == 0 ? vt : (mat == 1 ? qts : kts);
+    bf16_raw* outp = mat == 0 ? a.Vt : (mat == 1 ? a.Qt : a.Kt);
+    for (int id = threadIdx.x; id < 128 * 8; id += 256) {
+      const int d = id >> 3, c = id & 7;   // 8 tokens per 16-byte chunk
+      bf16_raw* dst = outp + (((long)b * a.H + hh) * HD + d) * a.Sp + a.s0 + t0 + c * 8;
+      if (c * 8 + 8 <= ntok && (((a.s0 + t0) & 7) == 0)) {
+        uint4 u;
+        u.x = (uint32_t)tile[c * 8 + 0][d] | ((uint32_t)tile[c * 8 + 1][d] << 16);
+        u.y = (uint32_t)tile[c * 8 + 2][d] | ((uint32_t)tile[c * 8 + 3][d] << 16);
+        u.z = (uint32_t)tile[c * 8 + 4][d] | ((uint32_t)tile[c * 8 + 5][d] << 16);
+        u.w = (uint32_t)tile[c * 8 + 6][d] | ((uint32_t)tile[c * 8 + 7][d] << 16);
+        *reinterpret_cast<uint4*>(dst) = u;
+      } else {
+        for (int j = 0; j < 8; ++j)
+          if (c * 8 + j < ntok) dst[j] = tile[c * 8 + j][d];
+      }
     }
   }
 }
 
-// backward: dQ, dK [B,H,S,128], dVt [B,H,128,Sp] -> dqkv [rows, 3*H*128]; per-block partial weight grads
+// backward: dQ, dK, dV [B,H,S,128] -> dqkv [rows, 3*H*128]; per-block partial weight grads
 struct QkBwdArgs {
   const bf16_raw* qkv;
   long ld;
@@ -283,29 +299,19 @@ struct QkBwdArgs {
   const float* sin;
   const bf16_raw* dQ;
   const bf16_raw* dK;
-  const bf16_raw* dVt;
+  const bf16_raw* dV;
   bf16_raw* dqkv;
   float* part;     // [nblocks][2][128]
   int H, S, Sp, rows_per_batch, s0;
 };
 
 __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
-  __shared__ bf16_raw vt[128][66];
   __shared__ float red[4][2][128];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int hh = blockIdx.y, b = blockIdx.z;
   const int t0 = blockIdx.x * 64;
   const int HD = 128;
   const long dmodel = (long)a.H * HD;
-  const int ntok = min(64, a.rows_per_batch - t0);
-  // stage dVt tile [128 d][64 tokens]
-  for (int id = threadIdx.x; id < 128 * 64; id += 256) {
-    const int d = id >> 6, tt = id & 63;
-    bf16_raw v = 0;
-    if (tt < ntok) v = a.dVt[(((long)b * a.H + hh) * HD + d) * a.Sp + a.s0 + t0 + tt];
-    vt[d][tt] = v;
-  }
-  __syncthreads();
   const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
   const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
   float gq0 = 0.f, gq1 = 0.f, gk0 = 0.f, gk1 = 0.f;
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
       const float dx1 = r * gz1 - x1 * r * r * r * dot;
       *reinterpret_cast<uint32_t*>(obase + which * dmodel) = (uint32_t)f2bf(dx0) | ((uint32_t)f2bf(dx1) << 16);
     }
-    *reinterpret_cast<uint32_t*>(obase + 2 * dmodel) = (uint32_t)vt[2 * lane][tl] | ((uint32_t)vt[2 * lane + 1][tl] << 16);
+    *reinterpret_cast<uint32_t*>(obase + 2 * dmodel) = *reinterpret_cast<const uint32_t*>(a.dV + o);
   }
   red[w][0][2 * lane] = gq0; red[w][0][2 * lane + 1] = gq1;
   red[w][1][2 * lane] = gk0; red[w][1][2 * lane + 1] = gk1;
@@ -413,13 +419,16 @@ extern "C" int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t
 }
 
 extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                                    const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int H, int S, int Sp,
-                                    int rows_per_batch, int s0, void* stream) {
+                                    const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
+                                    uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream) {
   MGX_REQUIRE(qkv && wq && wk && cos && sin && Q && K && Vt, "null argument");
+  MGX_REQUIRE((V != nullptr) == (Qt != nullptr) && (V != nullptr) == (Kt != nullptr), "V, Qt, Kt come together");
   MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Sp >= S, "bad sizes");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
-  QkArgs a{qkv, ld, wq, wk, cos, sin, Q, K, Vt, H, S, Sp, rows_per_batch, s0};
-  qk_norm_rope_fwd_kernel<<<dim3(cdiv(rows_per_batch, 64), H, B), 256, 0, (hipStream_t)stream>>>(a);
+  QkArgs a{qkv, ld, wq, wk, cos, sin, Q, K, Vt, V, Qt, Kt, H, S, Sp, rows_per_batch, s0};
+  dim3 grid(cdiv(rows_per_batch, 64), H, B);
+  if (V) qk_norm_rope_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else qk_norm_rope_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -429,13 +438,13 @@ extern "C" long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch)
 }
 
 extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                                    const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dVt,
+                                    const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
                                     uint16_t* dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp,
                                     int rows_per_batch, int s0, void* stream) {
-  MGX_REQUIRE(qkv && wq && wk && cos && sin && dQ && dK && dVt && dqkv && gwq && gwk && ws, "null argument");
+  MGX_REQUIRE(qkv && wq && wk && cos && sin && dQ && dK && dV && dqkv && gwq && gwk && ws, "null argument");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
   hipStream_t st = (hipStream_t)stream;
-  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dVt, dqkv, ws, H, S, Sp, rows_per_batch, s0};
+  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ws, H, S, Sp, rows_per_batch, s0};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
   qk_bwd_finish_kernel<<<2, 128, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);

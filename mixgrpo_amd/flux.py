@@ -88,8 +88,13 @@ def param_layout(cfg: FluxConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     for i in range(cfg.num_single_layers):
         p = f"single_transformer_blocks.{i}"
         lin(f"{p}.norm.linear", 3 * d, d)
-        qkv(f"{p}.attn", ("to_q", "to_k", "to_v"))
-        lin(f"{p}.proj_mlp", 4 * d, d)
+        # to_q | to_k | to_v | proj_mlp adjacent (weights, then biases): one [7d, d] operand for the backward GEMMs
+        for n in ("attn.to_q", "attn.to_k", "attn.to_v"):
+            out.append((f"{p}.{n}.weight", (d, d)))
+        out.append((f"{p}.proj_mlp.weight", (4 * d, d)))
+        for n in ("attn.to_q", "attn.to_k", "attn.to_v"):
+            out.append((f"{p}.{n}.bias", (d,)))
+        out.append((f"{p}.proj_mlp.bias", (4 * d,)))
         lin(f"{p}.proj_out", d, 5 * d)
         for n in ("norm_q", "norm_k"):
             out.append((f"{p}.attn.{n}.weight", (hd,)))
@@ -315,7 +320,7 @@ class FluxTransformer2DModel(torch.nn.Module):
             return Rows(t, w.B * w.L, width, w.L, w.S * width)
         return Rows(t[0, w.L:], w.B * w.N, width, w.N, w.S * width)
 
-    def _double_block(self, i, w, st, cos, sin, save=None):
+    def _double_block(self, i, w, st, cos, sin, save=None, mods_in=None):
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"transformer_blocks.{i}"
         B = w.B
@@ -326,18 +331,22 @@ class FluxTransformer2DModel(torch.nn.Module):
                     "to_add_out", "ff_context", w.L, 0))
         row0 = {"txt": 0, "img": w.B * w.L}     # row offsets inside the per-stream scratch buffers
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
-            m = torch.empty(B, 6 * d, dtype=BF16, device=dev)
-            ops.skinny_linear(st, self.W(f"{p}.{norm}.linear.weight"), self.W(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
+            if mods_in is not None:
+                m = mods_in[name]
+            else:
+                m = torch.empty(B, 6 * d, dtype=BF16, device=dev)
+                ops.skinny_linear(st, self.W(f"{p}.{norm}.linear.weight"), self.W(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
             mods[name] = m
             Xs = self._stream_rows(w.X, w, name, d)
             M = B * rows
-            nrm = w.nrm[row0[name]:row0[name] + M]
+            nrm = (w.nrm if save is None else save["nrm1"])[row0[name]:row0[name] + M]
             qkv = w.qkv[row0[name]:row0[name] + M]
             ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm, d)
             ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
                      self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv), 3 * d, d)
             ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
-                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0)
+                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
+                             **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         ops.attn_fwd(w.Q, w.K, w.Vt, w.O, w.lse if save is not None else None, B, H, w.S, w.Sp, d, w.S * d,
                      1.0 / math.sqrt(cfg.attention_head_dim))
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
@@ -345,17 +354,18 @@ class FluxTransformer2DModel(torch.nn.Module):
             M = B * rows
             Xs = self._stream_rows(w.X, w, name, d)
             Os = self._stream_rows(w.O, w, name, d)
-            nrm = w.nrm[row0[name]:row0[name] + M]
+            nrm = (w.nrm if save is None else save["nrm2"])[row0[name]:row0[name] + M]
             hid = w.hid[row0[name]:row0[name] + M]
             aux1 = aux2 = hpre = None
             if save is not None:
-                aux1 = save[f"{name}_y_attn"]
-                aux2 = save[f"{name}_y_ff"]
-                hpre = save[f"{name}_hid_pre"]
+                aux1 = save["y_attn"][row0[name]:row0[name] + M]
+                aux2 = save["y_ff"][row0[name]:row0[name] + M]
+                hpre = save["hid_pre"][row0[name]:row0[name] + M]
             ops.gemm(Os, self.W(f"{p}.attn.{outn}.weight"), self.W(f"{p}.attn.{outn}.bias"), Xs, d, d,
                      EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=6 * d, aux=aux1)
             if save is not None:
-                save[f"{name}_x_mid"].copy_(w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
+                (save["x_mid"][:, :w.L] if name == "txt" else save["x_mid"][:, w.L:]).copy_(
+                    w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
             ops.ln_modulate(Xs, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
             ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
                      Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
@@ -363,27 +373,33 @@ class FluxTransformer2DModel(torch.nn.Module):
                      EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
         return mods
 
-    def _single_block(self, i, w, st, cos, sin, save=None):
+    def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None):
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"single_transformer_blocks.{i}"
         B, S = w.B, w.S
         M = B * S
-        m = torch.empty(B, 3 * d, dtype=BF16, device=self.store.device)
-        ops.skinny_linear(st, self.W(f"{p}.norm.linear.weight"), self.W(f"{p}.norm.linear.bias"), m, 3 * d, d)
+        if mod_in is not None:
+            m = mod_in
+        else:
+            m = torch.empty(B, 3 * d, dtype=BF16, device=self.store.device)
+            ops.skinny_linear(st, self.W(f"{p}.norm.linear.weight"), self.W(f"{p}.norm.linear.bias"), m, 3 * d, d)
         Xa = Rows(w.X, M, d, S, S * d)
-        ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, w.nrm, d)
-        ops.gemm(Rows.of(w.nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
+        nrm = w.nrm if save is None else save["nrm1"]
+        ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, nrm, d)
+        ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
                  self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(w.qkv), 3 * d, d)
         cat2 = w.cat.view(M, 5 * d)
-        ops.gemm(Rows.of(w.nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
+        # the pre-activation (when kept) goes to columns 3d..7d of the [M, 7d] gradient staging buffer's twin
+        ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
                  Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
-                 aux=None if save is None else save["mlp_pre"], )
+                 aux=None if save is None else save["hid_pre"])
         ops.qk_norm_rope(w.qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
-                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0)
+                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
+                         **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         ops.attn_fwd(w.Q, w.K, w.Vt, w.cat, w.lse if save is not None else None, B, H, S, w.Sp, 5 * d, S * 5 * d,
                      1.0 / math.sqrt(cfg.attention_head_dim))
         ops.gemm(Rows.of(cat2), self.W(f"{p}.proj_out.weight"), self.W(f"{p}.proj_out.bias"), Xa, d, 5 * d,
-                 EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=3 * d, aux=None if save is None else save["y"])
+                 EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=3 * d, aux=None if save is None else save["y_attn"])
         return m
 
     def _embed(self, w, hidden_states, encoder_hidden_states):

@@ -1,0 +1,280 @@
+"""Backward pass of the HIP FLUX MMDiT with block-level activation recompute.
+
+Replaces `loss.backward()` through diffusers' FluxTransformer2DModel under FSDP + full activation
+checkpointing (reference fastvideo/train_grpo_flux.py:585, fastvideo/utils/fsdp_util.py:26-53): the forward
+keeps only each block's input (bf16 [B, S, d]); the backward re-runs one block at a time with its
+intermediates kept, then walks it in reverse.  Weight gradients accumulate in fp32 into the flat gradient
+buffer (MGX_EPI_F32_ACC, beta = 1); activation gradients are bf16 like autograd's.
+
+All arithmetic is in csrc/ kernels; this file only sequences them.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import BF16, F32, Rows, EPI_BIAS, EPI_BIAS_GATE_RES, EPI_DGELU, EPI_F32_ACC
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class _Train:
+    """Extra buffers for one (B, L, N) training problem."""
+
+    def __init__(self, cfg, w, device):
+        d, H, hd = cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
+        B, S, Sp = w.B, w.S, w.Sp
+        M = B * S
+        e = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=device)
+        z = lambda *shape, dtype=BF16: torch.zeros(*shape, dtype=dtype, device=device)
+        nblk = cfg.num_layers + cfg.num_single_layers
+        self.block_in = e(nblk, B, S, d)          # the only activations kept by the forward
+        self.x_final = e(B, S, d)
+        self.save = dict(nrm1=e(M, d), nrm2=e(M, d), y_attn=e(M, d), y_ff=e(M, d), hid_pre=e(M, 4 * d),
+                         x_mid=e(B, S, d), V=e(B, H, S, hd), Qt=z(B, H, hd, Sp), Kt=z(B, H, hd, Sp))
+        self.dX = e(B, S, d)
+        self.dO = e(B, S, 5 * d)                  # dO [B,S,d] view for double blocks, d(cat) [B,S,5d] for single
+        self.dQ, self.dK, self.dV = e(B, H, S, hd), e(B, H, S, hd), e(B, H, S, hd)
+        self.dOt = z(B, H, hd, Sp)
+        self.delta = e(B, H, S, dtype=F32)
+        self.dy = e(M, d)
+        self.dbig = e(M, 7 * d)                   # [dqkv | dmlp_pre] (single) / dqkv, dhid_pre (double)
+        self.dnrm = e(M, d)
+        Mp = _pad64(M)
+        self.dCt = e(7 * d * Mp)                  # transposed output-gradient operand for wgrad
+        self.At = e(5 * d * Mp)                   # transposed activation operand for wgrad
+        self.Wt = e(7 * d * max(d, 64) + 5 * d * d)
+        self.ones = torch.ones(1, 5 * d, dtype=BF16, device=device)
+
+
+class FluxFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat_param, model, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids,
+                pooled_projections, img_ids):
+        cfg = model.cfg
+        B, N, _ = hidden_states.shape
+        L = encoder_hidden_states.shape[1]
+        w = model._workspace(B, L, N)
+        tr = getattr(w, "train", None)
+        if tr is None:
+            tr = _Train(cfg, w, model.store.device)
+            w.train = tr
+        ehs = model._embed(w, hidden_states, encoder_hidden_states)
+        keep = {}
+        temb, st = model._temb(B, timestep.to(model.store.device), guidance, pooled_projections, keep=keep)
+        cos, sin = model._rope(txt_ids, img_ids)
+        mods = []
+        blk = 0
+        for i in range(cfg.num_layers):
+            tr.block_in[blk].copy_(w.X)
+            mods.append(model._double_block(i, w, st, cos, sin))
+            blk += 1
+        for i in range(cfg.num_single_layers):
+            tr.block_in[blk].copy_(w.X)
+            mods.append(model._single_block(i, w, st, cos, sin))
+            blk += 1
+        tr.x_final.copy_(w.X)
+        out, e = model._head(w, st)
+        ctx.model, ctx.w, ctx.tr = model, w, tr
+        ctx.saved = dict(ehs=ehs, in16=w.in16.clone(), temb=temb, st=st, keep=keep, cos=cos, sin=sin, mods=mods, e=e)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _backward(ctx.model, ctx.w, ctx.tr, ctx.saved, dout.contiguous().to(BF16))
+        return (None,) * 9
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _wgrad(model, tr, A: Rows, K, dC: Rows, N, wname, bname, rows=None):
+    """g32[W] += dC^T A ; g32[b] += colsum(dC).  `rows`: number of fused weight rows when W spans several tensors."""
+    st = model.store
+    g = st.ensure_grad()
+    M = A.M
+    Mp = _pad64(M)
+    dCt = tr.dCt[:N * Mp].view(N, Mp)
+    At = tr.At[:K * Mp].view(K, Mp)
+    gb = None
+    if bname is not None:
+        gb = st.fused(g, bname, N) if rows else st.view(g, bname)
+    ops.transpose(dC, N, dCt, Mp, colsum_out=gb, colsum_beta=1.0)
+    ops.transpose(A, K, At, Mp)
+    gw = st.fused(g, wname, N) if rows else st.view(g, wname)
+    ops.gemm(Rows.of(dCt), At, None, Rows(gw, N, K), K, Mp, EPI_F32_ACC, beta=1.0, ldw=Mp)
+
+
+def _dgrad(model, tr, dC: Rows, N, K, wname, out: Rows, rows=None, epi=EPI_BIAS, aux=None, ldaux=None, row_lo=0,
+           row_hi=None, gate=None):
+    """out[M, K'] = epi(dC[M, N] @ W[N, K][:, row_lo:row_hi]) via a transposed copy of W (K-contiguous operand)."""
+    st = model.store
+    W = st.fused(st.w16, wname, N) if rows else st.view(st.w16, wname)
+    Wt = tr.Wt[:K * N].view(K, N)
+    ops.transpose(Rows.of(W), K, Wt, N)
+    row_hi = K if row_hi is None else row_hi
+    ops.gemm(dC, Wt[row_lo:row_hi], None, out, row_hi - row_lo, N, epi, aux=aux, ldaux=ldaux, gate=gate, gate_ld=0)
+
+
+def _skinny_bwd(model, tr, dmod, x, wname, bname, N, K, dx_acc):
+    """Modulation / embedder linear backward: g32[W] += dmod^T x, g32[b] += sum_b dmod, dx_acc += dmod @ W."""
+    st = model.store
+    g = st.ensure_grad()
+    ops.skinny_wgrad(dmod, x, st.view(g, wname), st.view(g, bname), N, K)
+    if dx_acc is not None:
+        Bn = dmod.shape[0]
+        tmp = torch.empty(Bn, K, dtype=BF16, device=dmod.device)
+        _dgrad(model, tr, Rows.of(dmod), N, K, wname, Rows.of(tmp))
+        ops.ew(tmp, None, dx_acc, 3)
+
+
+def _backward(model, w, tr, sv, dout):
+    cfg = model.cfg
+    d, H = cfg.dim, cfg.num_attention_heads
+    B, L, N, S, Sp = w.B, w.L, w.N, w.S, w.Sp
+    M = B * S
+    dev = model.store.device
+    st_, cos, sin = sv["st"], sv["cos"], sv["sin"]
+    scale = 1.0 / math.sqrt(cfg.attention_head_dim)
+    store = model.store
+    g32 = store.ensure_grad()
+    dst = torch.zeros(B, d, dtype=BF16, device=dev)        # grad wrt st = silu(temb), summed over all users
+    save = tr.save
+    row0 = {"txt": 0, "img": B * L}
+
+    def srows(t, which, width):
+        return model._stream_rows(t, w, which, width)
+
+    # ---------------- head: out = proj_out( LN(x_img) * (1+scale) + shift )
+    cout = cfg.patch_size * cfg.patch_size * cfg.in_channels
+    e = sv["e"]
+    nrm = save["nrm1"][:B * N]
+    ops.ln_modulate(srows(tr.x_final, "img", d), e[:, d:2 * d], e[:, 0:d], 2 * d, nrm, d)
+    dC = Rows.of(dout.view(B * N, cout))
+    _wgrad(model, tr, Rows.of(nrm), d, dC, cout, "proj_out.weight", "proj_out.bias")
+    dn = tr.dnrm[:B * N]
+    _dgrad(model, tr, dC, cout, d, "proj_out.weight", Rows.of(dn))
+    tr.dX.zero_()
+    de = torch.zeros(B, 2 * d, dtype=BF16, device=dev)
+    ops.ln_modulate_bwd(dn, srows(tr.x_final, "img", d), e[:, 0:d], 2 * d, srows(tr.dX, "img", d), False,
+                        de[:, d:2 * d], de[:, 0:d], d)
+    _skinny_bwd(model, tr, de, st_, "norm_out.linear.weight", "norm_out.linear.bias", 2 * d, d, dst)
+
+    nblk = cfg.num_layers + cfg.num_single_layers
+    # ---------------- single blocks (reverse)
+    for i in reversed(range(cfg.num_single_layers)):
+        blk = cfg.num_layers + i
+        p = f"single_transformer_blocks.{i}"
+        m = sv["mods"][blk]
+        w.X.copy_(tr.block_in[blk])
+        model._single_block(i, w, st_, cos, sin, save=save, mod_in=m)
+        dmod = torch.empty(B, 3 * d, dtype=BF16, device=dev)
+        x_in = Rows(tr.block_in[blk], M, d, S, S * d)
+        dXr = Rows(tr.dX, M, d, S, S * d)
+        cat2 = w.cat.view(M, 5 * d)
+        # out = x + gate * y ; y = proj_out(cat)
+        ops.gate_bwd(dXr, save["y_attn"], m[:, 2 * d:3 * d], 3 * d, tr.dy, dmod[:, 2 * d:3 * d], B, S, d)
+        dyr = Rows.of(tr.dy)
+        _wgrad(model, tr, Rows.of(cat2), 5 * d, dyr, d, f"{p}.proj_out.weight", f"{p}.proj_out.bias")
+        dcat = tr.dO.view(M, 5 * d)
+        dbig = tr.dbig                                         # [M, 7d] = [dq | dk | dv | dmlp_pre]
+        # d(cat)[:, :d] = dO (attention output grad) ; d(cat)[:, d:] -> through GELU -> dbig[:, 3d:]
+        Wt_full = None
+        stW = store.view(store.w16, f"{p}.proj_out.weight")
+        Wt = tr.Wt[:5 * d * d].view(5 * d, d)
+        ops.transpose(Rows.of(stW), 5 * d, Wt, d)
+        ops.gemm(dyr, Wt[0:d], None, Rows(dcat, M, 5 * d), d, d, EPI_BIAS)
+        ops.gemm(dyr, Wt[d:5 * d], None, Rows(dbig[0, 3 * d:], M, 7 * d), 4 * d, d, EPI_DGELU, aux=save["hid_pre"],
+                 ldaux=4 * d)
+        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, w.lse, tr.delta, tr.dOt, tr.dQ, tr.dK,
+                     tr.dV, B, H, S, Sp, 5 * d, S * 5 * d, scale)
+        # qk norm / rope backward writes [dq|dk|dv] into a [M, 3d] matrix: stage through qkv-shaped scratch, then
+        # place it in dbig[:, :3d]
+        dqkv = tr.dCt[:M * 3 * d].view(M, 3 * d)
+        ops.qk_norm_rope_bwd(w.qkv, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
+                             tr.dQ, tr.dK, tr.dV, dqkv, store.view(g32, f"{p}.attn.norm_q.weight"),
+                             store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0)
+        dbig[:, :3 * d].copy_(dqkv)
+        dbr = Rows.of(dbig)
+        _wgrad(model, tr, Rows.of(save["nrm1"]), d, dbr, 7 * d, f"{p}.attn.to_q.weight", f"{p}.attn.to_q.bias", rows=True)
+        _dgrad(model, tr, dbr, 7 * d, d, f"{p}.attn.to_q.weight", Rows.of(tr.dnrm), rows=True)
+        ops.ln_modulate_bwd(tr.dnrm, x_in, m[:, d:2 * d], 3 * d, dXr, True, dmod[:, 0:d], dmod[:, d:2 * d], d)
+        _skinny_bwd(model, tr, dmod, st_, f"{p}.norm.linear.weight", f"{p}.norm.linear.bias", 3 * d, d, dst)
+
+    # ---------------- double blocks (reverse)
+    streams = (("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", N, L),
+               ("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
+                "to_add_out", "ff_context", L, 0))
+    dO3 = tr.dO.view(-1)[:B * S * d].view(B, S, d)
+    for i in reversed(range(cfg.num_layers)):
+        p = f"transformer_blocks.{i}"
+        mods = sv["mods"][i]
+        w.X.copy_(tr.block_in[i])
+        model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods)
+        dmods = {k: torch.empty(B, 6 * d, dtype=BF16, device=dev) for k in ("img", "txt")}
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            m, dm = mods[name], dmods[name]
+            Ms = B * rows
+            r0 = row0[name]
+            dXs = srows(tr.dX, name, d)
+            sl = slice(r0, r0 + Ms)
+            # ---- FF branch: out = x_mid + gate_mlp * ff2(gelu(ff1(LNmod(x_mid))))
+            ops.gate_bwd(dXs, save["y_ff"][sl], m[:, 5 * d:6 * d], 6 * d, tr.dy[sl], dm[:, 5 * d:6 * d], B, rows, d)
+            dyr = Rows.of(tr.dy[sl])
+            hid = w.hid[sl]
+            _wgrad(model, tr, Rows.of(hid), 4 * d, dyr, d, f"{p}.{ffn}.net.2.weight", f"{p}.{ffn}.net.2.bias")
+            dh = tr.dbig.view(-1)[:M * 4 * d].view(M, 4 * d)[sl]
+            _dgrad(model, tr, dyr, d, 4 * d, f"{p}.{ffn}.net.2.weight", Rows.of(dh), epi=EPI_DGELU,
+                   aux=save["hid_pre"][sl], ldaux=4 * d)
+            nrm2 = save["nrm2"][sl]
+            _wgrad(model, tr, Rows.of(nrm2), d, Rows.of(dh), 4 * d, f"{p}.{ffn}.net.0.proj.weight",
+                   f"{p}.{ffn}.net.0.proj.bias")
+            dn = tr.dnrm[sl]
+            _dgrad(model, tr, Rows.of(dh), 4 * d, d, f"{p}.{ffn}.net.0.proj.weight", Rows.of(dn))
+            ops.ln_modulate_bwd(dn, srows(save["x_mid"], name, d), m[:, 4 * d:5 * d], 6 * d, dXs, True,
+                                dm[:, 3 * d:4 * d], dm[:, 4 * d:5 * d], d)
+            # ---- attention branch: x_mid = x_in + gate_msa * to_out(O)
+            ops.gate_bwd(dXs, save["y_attn"][sl], m[:, 2 * d:3 * d], 6 * d, tr.dy[sl], dm[:, 2 * d:3 * d], B, rows, d)
+            _wgrad(model, tr, srows(w.O, name, d), d, dyr, d, f"{p}.attn.{outn}.weight", f"{p}.attn.{outn}.bias")
+            _dgrad(model, tr, dyr, d, d, f"{p}.attn.{outn}.weight", srows(dO3, name, d))
+        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.O, dO3, w.lse, tr.delta, tr.dOt, tr.dQ, tr.dK, tr.dV,
+                     B, H, S, Sp, d, S * d, scale)
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            m, dm = mods[name], dmods[name]
+            Ms = B * rows
+            r0 = row0[name]
+            sl = slice(r0, r0 + Ms)
+            dXs = srows(tr.dX, name, d)
+            dqkv = tr.dbig.view(-1)[:M * 3 * d].view(M, 3 * d)[sl]
+            ops.qk_norm_rope_bwd(w.qkv[sl], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
+                                 sin, tr.dQ, tr.dK, tr.dV, dqkv, store.view(g32, f"{p}.attn.{nq}.weight"),
+                                 store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0)
+            nrm1 = save["nrm1"][sl]
+            _wgrad(model, tr, Rows.of(nrm1), d, Rows.of(dqkv), 3 * d, f"{p}.attn.{qkvn[0]}.weight",
+                   f"{p}.attn.{qkvn[0]}.bias", rows=True)
+            dn = tr.dnrm[sl]
+            _dgrad(model, tr, Rows.of(dqkv), 3 * d, d, f"{p}.attn.{qkvn[0]}.weight", Rows.of(dn), rows=True)
+            ops.ln_modulate_bwd(dn, srows(tr.block_in[i], name, d), m[:, d:2 * d], 6 * d, dXs, True, dm[:, 0:d],
+                                dm[:, d:2 * d], d)
+            _skinny_bwd(model, tr, dm, st_, f"{p}.{norm}.linear.weight", f"{p}.{norm}.linear.bias", 6 * d, d, dst)
+
+    # ---------------- embedders (inputs need no gradient)
+    _wgrad(model, tr, Rows.of(sv["in16"]), cfg.in_channels, srows(tr.dX, "img", d), d, "x_embedder.weight",
+           "x_embedder.bias")
+    _wgrad(model, tr, Rows.of(sv["ehs"].view(B * L, -1)), cfg.joint_attention_dim, srows(tr.dX, "txt", d), d,
+           "context_embedder.weight", "context_embedder.bias")
+
+    # ---------------- temb path: st = silu(temb); temb = sum of three MLP outputs
+    dtemb = torch.empty(B, d, dtype=BF16, device=dev)
+    ops.ew(sv["temb"], dst, dtemb, 1)
+    for name, (x, h1, a1) in sv["keep"].items():
+        K = x.shape[1]
+        da1 = torch.zeros(B, d, dtype=BF16, device=dev)
+        _skinny_bwd(model, tr, dtemb, a1, f"time_text_embed.{name}.linear_2.weight",
+                    f"time_text_embed.{name}.linear_2.bias", d, d, da1)
+        dh1 = torch.empty(B, d, dtype=BF16, device=dev)
+        ops.ew(h1, da1, dh1, 1)
+        _skinny_bwd(model, tr, dh1, x, f"time_text_embed.{name}.linear_1.weight",
+                    f"time_text_embed.{name}.linear_1.bias", d, K, None)
+    if model.flat_param.grad is None:
+        model.flat_param.grad = g32

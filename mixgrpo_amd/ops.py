@@ -27,11 +27,12 @@ class Rows:
         return Rows(t, t.numel() // cols, cols)
 
 
-def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, aux=None, beta=0.0, ldw=None):
-    """C = epi(A @ W[N,K]^T + bias).  `aux` shares C's row map."""
+def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, aux=None, beta=0.0, ldw=None, ldaux=None):
+    """C = epi(A @ W[N,K]^T + bias).  `aux`: plain [M, ldaux] matrix (ldaux defaults to N); pass a tensor whose
+    data_ptr() is its first element."""
     assert A.M == C.M
     check(lib().mgx_gemm_bf16(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), None if gate is None else gate.data_ptr(),
-                              ptr(aux), A.M, N, K, A.ld, A.rpb,
+                              None if aux is None else aux.data_ptr(), (N if ldaux is None else ldaux), A.M, N, K, A.ld, A.rpb,
                               A.bstride, K if ldw is None else ldw, C.ld, C.rpb, C.bstride, gate_ld, epi, beta, stream()))
 
 
@@ -70,15 +71,15 @@ def ln_modulate_bwd(dy, x: Rows, scale, mod_ld, dx: Rows, accumulate, dshift, ds
                                     dscale.data_ptr(), ptr(ws), x.M, D, stream()))
 
 
-def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s0):
+def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s0, V=None, Qt=None, Kt=None):
     check(lib().mgx_qk_norm_rope_fwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K), ptr(Vt),
-                                     B, H, S, Sp, rows_per_batch, s0, stream()))
+                                     ptr(V), ptr(Qt), ptr(Kt), B, H, S, Sp, rows_per_batch, s0, stream()))
 
 
-def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dVt, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0):
+def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0):
     ws = scratch("qk_bwd", lib().mgx_qk_norm_rope_bwd_workspace(B, H, rows_per_batch), F32, qkv.device)
     check(lib().mgx_qk_norm_rope_bwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
-                                     ptr(dVt), ptr(dqkv), ptr(gwq), ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0,
+                                     ptr(dV), ptr(dqkv), ptr(gwq), ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0,
                                      stream()))
 
 
@@ -130,3 +131,8 @@ def sqnorm(g, out, beta=0.0):
 def adamw_step(w, w16, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, grad_scale=1.0):
     check(lib().mgx_adamw_step(ptr(w), ptr(w16), ptr(g), ptr(m), ptr(v), w.numel(), lr, beta1, beta2, eps, wd, step,
                                ptr(gnorm_sq), max_norm, grad_scale, stream()))
+
+
+def attn_bwd(Q, K, V, Qt, Kt, O, dO, lse, delta, dOt, dQ, dK, dV, B, H, S, Sp, ldo, o_bstride, scale):
+    check(lib().mgx_attn_bwd(ptr(Q), ptr(K), ptr(V), ptr(Qt), ptr(Kt), O.data_ptr(), dO.data_ptr(), ptr(lse), ptr(delta),
+                             ptr(dOt), ptr(dQ), ptr(dK), ptr(dV), B, H, S, Sp, ldo, o_bstride, scale, stream()))

@@ -100,3 +100,68 @@ def test_attention_kernel_vs_torch():
     ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, S, H * 128)
     assert rel_err(O, ref) < 6e-3
     assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,hg,wg,L", [(1, 8, 8, 64), (2, 6, 10, 24)])
+def test_backward_vs_oracle_autograd(B, hg, wg, L):
+    """d(sum(out * R))/d(params) through the HIP backward (block recompute) vs torch autograd of the oracle.
+    Activation grads are bf16 on both sides (different rounding points): per-tensor relative L2 error <= 4e-2,
+    and the global gradient direction must agree to cosine >= 0.999."""
+    ocfg, P, m = build_pair(small_cfg(2, 2))
+    x, ehs, pooled, ids, tids, t, gd = make_inputs(B, hg, wg, L, seed=3)
+    R = torch.randn(B, hg * wg, 64, generator=torch.Generator().manual_seed(9))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = OM.forward(Pg, ocfg, x, ehs.float(), t, gd.float(), tids, pooled.float(), ids)
+    (ref * R).sum().backward()
+    m.train()
+    out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
+    assert out.requires_grad
+    (out.float() * R.cuda()).sum().backward()
+    g = m.store.g32
+    assert m.flat_param.grad is g
+    dots = nh = no = 0.0
+    worst = []
+    for k in P:
+        gh = m.store.view(g, k).float().cpu()
+        go = Pg[k].grad
+        dots += (gh * go).sum().item()
+        nh += gh.pow(2).sum().item()
+        no += go.pow(2).sum().item()
+        e = ((gh - go).norm() / (go.norm() + 1e-9)).item()
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    cos = dots / math.sqrt(nh * no)
+    assert cos > 0.999, (cos, worst[:5])
+    assert worst[0][0] < 4e-2, worst[:8]
+    # a second backward accumulates (gradient accumulation over replayed steps)
+    out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
+    (out.float() * R.cuda()).sum().backward()
+    k0 = "transformer_blocks.0.ff.net.2.weight"
+    assert rel_err(m.store.view(g, k0), 2 * Pg[k0].grad) < 4e-2
+
+
+def test_attention_backward_vs_torch():
+    from mixgrpo_amd import ops
+    B, H, S = 1, 2, 700
+    Sp = (S + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    do = torch.randn(B, S, H * 128, device="cuda", generator=g).bfloat16()
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) / math.sqrt(128)
+    o_ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, S, H * 128)
+    o_ref.backward(do.float())
+    pad = lambda t: torch.cat([t.transpose(-1, -2), torch.zeros(B, H, 128, Sp - S, device="cuda", dtype=t.dtype)], -1).contiguous()
+    vt, qt, kt = pad(v), pad(q), pad(k)
+    O = torch.empty(B, S, H * 128, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attn_fwd(q, k, vt, O, lse, B, H, S, Sp, H * 128, S * H * 128, 1 / math.sqrt(128))
+    dQ, dK, dV = (torch.empty_like(q) for _ in range(3))
+    delta = torch.empty(B, H, S, device="cuda")
+    dOt = torch.zeros(B, H, 128, Sp, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(q, k, v, qt, kt, O, do, lse, delta, dOt, dQ, dK, dV, B, H, S, Sp, H * 128, S * H * 128, 1 / math.sqrt(128))
+    assert rel_err(dV, vf.grad) < 1e-2
+    assert rel_err(dK, kf.grad) < 1.5e-2
+    assert rel_err(dQ, qf.grad) < 1.5e-2
