@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""GRPO train-step throughput (images/sec) of the MI355X-native MixGRPO engine on FLUX.1-dev 1024^2.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one `train_one_step` (BASELINE.json metric): group rollout (G x T MMDiT forwards + solver steps),
+reward gather, group-relative advantages, G x W replayed forward/backward passes, optimizer steps every `accum`
+samples.  Synthetic inputs: random-init FLUX.1-dev weights (N(0, 0.02^2)), 1024x1024 latents,
+cached-text-embedding-shaped random tensors, uniform synthetic rewards.  Excluded: VAE decode,
+reward-model inference, image/wandb logging, checkpointing.  One rank per GPU, weak scaling (one prompt group per
+rank per step, like the reference's DistributedSampler partitioning).
+
+Prints ONE JSON line on rank 0, with `roofline` (bf16 MFMA GEMM family, measured with HIP events around every
+GEMM launch of one extra, untimed train step) and `cpu_baseline` (the CPU oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+F_FWD_1024 = 74.38e12              # algorithmic FLOPs of one FLUX.1-dev forward at 1024^2
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "flux1dev_1024_T25_W4_G8": dict(h=1024, w=1024, sampling_steps=25, window=4, num_generations=8,
+                                    gradient_accumulation_steps=3, layers=(19, 38), heads=24, txt=512),
+    # a small stand-in for quick checks (NOT the metric): 2+2 blocks, 256^2
+    "tiny_256_T8_W2_G4": dict(h=256, w=256, sampling_steps=8, window=2, num_generations=4,
+                              gradient_accumulation_steps=2, layers=(2, 2), heads=24, txt=64),
+}
+
+
+def flops_per_forward(cfg, n_img, n_txt):
+    d = cfg.dim
+    S = n_img + n_txt
+    lin = 0
+    lin += cfg.num_layers * (12 * d * d * S + 2 * 6 * d * d)          # qkv+out (4 d^2) + ff (8 d^2) per token, both streams
+    lin += cfg.num_single_layers * (12 * d * d * S + 3 * d * d)      # qkv (3) + mlp (4) + out (5) = 12 d^2 per token
+    attn = (cfg.num_layers + cfg.num_single_layers) * 2 * S * S * d
+    emb = n_img * cfg.in_channels * d * 2 + n_txt * cfg.joint_attention_dim * d
+    return 2.0 * (lin + attn + emb)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="flux1dev_1024_T25_W4_G8", choices=list(WORKLOADS))
+    ap.add_argument("--train-microbatch", type=int, default=6)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from mixgrpo_amd import ops
+    from mixgrpo_amd import train_grpo_flux as TG
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    from mixgrpo_amd.grpo_states import GRPOTrainingStates
+    from mixgrpo_amd.optim import ConstantWithWarmup, FusedAdamW
+
+    wl = WORKLOADS[a.workload]
+    cfg = FluxConfig(num_layers=wl["layers"][0], num_single_layers=wl["layers"][1], num_attention_heads=wl["heads"])
+    model = FluxTransformer2DModel(cfg, device=dev).init_synthetic(seed=0, std=0.02)
+    opt = FusedAdamW(model, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+    sched = ConstantWithWarmup(opt, 0)
+    args = TG.default_args(h=wl["h"], w=wl["w"], sampling_steps=wl["sampling_steps"], num_generations=wl["num_generations"],
+                           gradient_accumulation_steps=wl["gradient_accumulation_steps"], train_microbatch=a.train_microbatch)
+    T, G, W = args.sampling_steps, args.num_generations, wl["window"]
+    states = GRPOTrainingStates(iters_per_group=25, group_size=W, max_timesteps=T - 2, prog_overlap=True,
+                                prog_overlap_step=1, roll_back=True)
+    torch.manual_seed(714 + rank)
+    n_img = (args.h // 16) * (args.w // 16)
+    L = wl["txt"]
+
+    def loader():
+        g = torch.Generator(device=dev).manual_seed(714 + rank)
+        while True:
+            yield ((0.1 * torch.randn(1, L, cfg.joint_attention_dim, device=dev, generator=g)).bfloat16(),
+                   torch.randn(1, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16(),
+                   torch.zeros(1, 3, device=dev), ["synthetic prompt"])
+
+    step_no = [0]
+
+    def reward_fn(latents, captions):
+        g = torch.Generator().manual_seed(1234 + step_no[0] * 131 + rank)
+        r = torch.rand(latents.shape[0], generator=g)
+        return r, {"SyntheticReward": r}
+
+    it = loader()
+
+    def one_step():
+        window = states.get_current_timesteps()
+        states.update_iteration()
+        out = TG.train_one_step(args, dev, model, None, reward_fn, opt, sched, it, None, 1.0, window, step_no[0],
+                                {"SyntheticReward": 1.0})
+        step_no[0] += 1
+        return out, window
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(a.warmup):
+        last = one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    images = world * G * a.steps
+    value = images / dt
+    f_fwd = flops_per_forward(cfg, n_img, L)
+    flop_img = (T + 3 * W) * f_fwd                      # algorithmic (recompute not counted), SURVEY.md 8d
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        ops.GEMM_PROFILE = []
+        one_step()
+        torch.cuda.synchronize()
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ops.GEMM_PROFILE)
+        tot_fl = sum(f for _, _, f in ops.GEMM_PROFILE)
+        n_launch = len(ops.GEMM_PROFILE)
+        ops.GEMM_PROFILE = None
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<EPI> (bf16 MFMA 128x128x64, all epilogues)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n_launch,
+                    "avg_launch_ms": round(tot_ms / max(1, n_launch), 4),
+                    "gemm_share_of_step": round(tot_ms * 1e-3 / (dt / a.steps), 3),
+                    "train_step_frac_of_peak": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
+    elif world > 1 and not a.no_roofline:
+        pass
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if not a.no_cpu_baseline and rank == 0:
+        cpu = cpu_baseline(flop_img)
+
+    if rank == 0:
+        line = {"metric": "GRPO train-step images/sec, FLUX.1-dev 1024^2", "value": round(value, 5), "unit": "images/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 1),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": a.workload, "model": "FLUX.1-dev (random-init, 11.9B)" if wl["layers"] == (19, 38)
+                           else f"FLUX-like {wl['layers']} blocks", "resolution": f"{args.h}x{args.w}",
+                           "sampling_steps": T, "sde_window": last[1] if last else None, "group_size": G,
+                           "grad_accum": args.gradient_accumulation_steps, "global_batch": world * G,
+                           "seq_len": n_img + L, "parallelism": f"dp{world}", "train_microbatch": a.train_microbatch,
+                           "algorithmic_pflop_per_image": round(flop_img / 1e15, 3)},
+                "images_per_sec_per_gpu": round(value / world, 5),
+                "mfma_frac_train_step": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+                "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4]} if last else None,
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(flop_img):
+    """The CPU oracle (a port: kind "port") timed on this box's host cores on a bounded sample of the workload:
+    one full-width (d=3072, 24 heads) MMDiT forward with 1 double + 1 single block on 1024 image + 512 text
+    tokens, and one full-size solver step; images/s is EXTRAPOLATED by algorithmic FLOPs to the 25/4 train step."""
+    import torch
+    from oracle import mmdit as OM
+    from oracle import solver as OS
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    cfg = OM.FluxConfig(num_layers=1, num_single_layers=1)
+    P = OM.init_params(cfg, seed=0)
+    N, L = 1024, 512
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, N, 64, generator=g)
+    ehs = 0.1 * torch.randn(1, L, 4096, generator=g)
+    pooled = torch.randn(1, 768, generator=g)
+    ids = torch.zeros(32, 32, 3)
+    ids[..., 1] += torch.arange(32)[:, None]
+    ids[..., 2] += torch.arange(32)[None]
+    ids = ids.reshape(N, 3)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        OM.forward(P, cfg, x, ehs, torch.tensor([0.954]), torch.tensor([3.5]), torch.zeros(L, 3), pooled, ids)
+        t_fwd = time.perf_counter() - t0
+    fl = flops_per_forward(cfg, N, L)
+    rate = fl / t_fwd
+    xs = torch.randn(1, 4096, 64, generator=g)
+    v = torch.randn(1, 4096, 64, generator=g).bfloat16()
+    sig = OS.sd3_time_shift(3.0, torch.linspace(1, 0, 26))
+    t0 = time.perf_counter()
+    for _ in range(20):
+        OS.flow_grpo_step(v, xs, 0.7, sig, 3, None)
+    t_solver = (time.perf_counter() - t0) / 20
+    sec_per_image = flop_img / rate + 25 * t_solver
+    return {"value": round(1.0 / sec_per_image, 8), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle MMDiT forward d=3072, 1 double+1 single block, {N}+{L} tokens: {t_fwd:.2f}s = "
+                      f"{rate / 1e12:.3f} TFLOP/s; full-size solver step {t_solver * 1e3:.2f} ms; images/s extrapolated "
+                      f"by algorithmic FLOPs to the T=25/W=4 train step ({flop_img / 1e15:.3f} PFLOP/image)"}
+
+
+if __name__ == "__main__":
+    main()

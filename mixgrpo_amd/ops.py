@@ -31,6 +31,20 @@ def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, au
     """C = epi(A @ W[N,K]^T + bias).  `aux`: plain [M, ldaux] matrix (ldaux defaults to N); pass a tensor whose
     data_ptr() is its first element."""
     assert A.M == C.M
+    if GEMM_PROFILE is not None:     # bench.py: HIP events around every GEMM launch on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux)
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * A.M * N * K))
+        return
+    _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux)
+
+
+GEMM_PROFILE = None
+
+
+def _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux):
     check(lib().mgx_gemm_bf16(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), None if gate is None else gate.data_ptr(),
                               None if aux is None else aux.data_ptr(), (N if ldaux is None else ldaux), A.M, N, K, A.ld, A.rpb,
                               A.bstride, K if ldw is None else ldw, C.ld, C.rpb, C.bstride, gate_ld, epi, beta, stream()))

@@ -61,14 +61,14 @@ def _avg(t):
     return t.item()
 
 
-def sample_group(args, transformer, ehs, pooled, text_ids, window, reward_fn):
+def sample_group(args, transformer, ehs, pooled, text_ids, window, reward_fn, injected=None):
     """G sequential batch-1 rollouts sharing x_T when init_same_noise (train_grpo_flux.py:184-329)."""
     T = args.sampling_steps
     sigmas = S.sd3_time_shift(args.shift, torch.linspace(1, 0, T + 1))
     lh, lw = args.h // 8, args.w // 8
     B = ehs.shape[0]
     if args.init_same_noise:
-        x_T = torch.randn((1, 16, lh, lw), dtype=torch.bfloat16)
+        x_T = injected["x_T"] if injected else torch.randn((1, 16, lh, lw), dtype=torch.bfloat16)
     lat_all, lp_all, ids_all, tot_all, head_all = [], [], [], [], {}
     for i in range(B):
         if not args.init_same_noise:
@@ -81,7 +81,8 @@ def sample_group(args, transformer, ehs, pooled, text_ids, window, reward_fn):
             det = [False] * T
         with torch.no_grad():
             _, latents, bl, blp = R.run_sample_step(args, z0, range(T), sigmas, transformer, ehs[i:i + 1],
-                                                    pooled[i:i + 1], text_ids[i:i + 1], ids, True, det)
+                                                    pooled[i:i + 1], text_ids[i:i + 1], ids, True, det,
+                                                    noises=[n[i:i + 1] for n in injected["steps"]] if injected else None)
         lat_all.append(bl)
         lp_all.append(blp)
         ids_all.append(ids)
@@ -143,7 +144,7 @@ def replay_log_prob(args, transformer, latents, next_latents, ehs, pooled, text_
 
 
 def train_one_step(args, transformer, optimizer, lr_scheduler, batch, reward_fn, reward_weights, window,
-                   max_grad_norm, trace=None):
+                   max_grad_norm, trace=None, injected=None):
     """Returns (total_loss, grad_norm, policy_total_loss, kl_total_loss, total_clip_frac, reward_mean)."""
     tot = pol = klt = clip_t = 0.0
     optimizer.zero_grad()
@@ -151,7 +152,8 @@ def train_one_step(args, transformer, optimizer, lr_scheduler, batch, reward_fn,
     G = args.num_generations
     if args.use_group:
         ehs, pooled, text_ids = (torch.repeat_interleave(t, G, dim=0) for t in (ehs, pooled, text_ids))
-    rewards, all_lat, all_lp, sigmas, all_ids = sample_group(args, transformer, ehs, pooled, text_ids, window, reward_fn)
+    rewards, all_lat, all_lp, sigmas, all_ids = sample_group(args, transformer, ehs, pooled, text_ids, window, reward_fn,
+                                                             injected=injected)
     B = all_lat.shape[0]
     T = args.sampling_steps
     tsv = [int(s * 1000) for s in sigmas][:T]
