@@ -184,7 +184,12 @@ def _fused_step(transformer, optimizer, max_grad_norm):
         nsq = optimizer.grad_sqnorm()
         optimizer.step(max_grad_norm=max_grad_norm, grad_scale=1.0 / ws)
         return nsq.sqrt().squeeze(0) / ws
-    gn = transformer.clip_grad_norm_(max_grad_norm)   # foreign model/optimizer: the reference's own sequence
+    if ws > 1:                                        # foreign model: average the per-parameter grads over ranks
+        for prm in transformer.parameters():
+            if prm.grad is not None:
+                dist.all_reduce(prm.grad, op=dist.ReduceOp.SUM)
+                prm.grad.div_(ws)
+    gn = transformer.clip_grad_norm_(max_grad_norm)   # then the reference's own sequence (:606-607)
     optimizer.step()
     return gn
 

@@ -1,0 +1,76 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: reward all-gather, bucketed gradient all-reduce,
+logging-vector averaging, per-rank prompt partitioning and the DP-equivalence of averaged gradients."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixgrpo_amd import dist_utils as DU
+    out = {}
+    # rewards: each rank owns one whole group of G=4 (reference partitioning) -> gathered [world*G]
+    r = torch.arange(4, dtype=torch.float32) + 10 * rank
+    out["gathered"] = DU.gather_tensor(r).tolist()
+    # flat gradient buffer reduced in several buckets (sizes that do not divide evenly)
+    g = torch.full((1000,), float(rank + 1))
+    g[::7] += rank
+    DU.allreduce_sum_(g, bucket_elems=300)
+    out["gsum_head"] = g[:8].tolist()
+    works = DU.allreduce_sum_(torch.ones(10), async_op=True)
+    for w in works:
+        w.wait()
+    v = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
+    out["mean_vec"] = DU.allreduce_mean_vec_(v).tolist()
+    out["rank_world"] = (DU.rank(), DU.world_size(), DU.is_dist())
+    # DP equivalence: mean of per-rank grads == grad of the mean loss over the union of the two shards
+    torch.manual_seed(0)
+    w0 = torch.randn(5, requires_grad=True)
+    x = torch.randn(2, 3, 5)[rank]
+    (x @ w0).pow(2).mean().backward()
+    gl = w0.grad.clone()
+    dist.all_reduce(gl)
+    gl /= world
+    out["dp_grad"] = gl.tolist()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rk in (0, 1):
+        o = res[rk]
+        assert o["gathered"] == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]
+        assert o["gsum_head"] == [4.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 4.0]
+        assert o["mean_vec"] == [1.5, 3.0, 4.5, 6.0]
+        assert o["rank_world"] == (rk, 2, True)
+    # reference: full-batch gradient of the mean of the two per-shard losses
+    torch.manual_seed(0)
+    w0 = torch.randn(5, requires_grad=True)
+    xs = torch.randn(2, 3, 5)
+    (0.5 * ((xs[0] @ w0).pow(2).mean() + (xs[1] @ w0).pow(2).mean())).backward()
+    assert torch.allclose(torch.tensor(res[0]["dp_grad"]), w0.grad, atol=1e-6)
+    assert res[0]["dp_grad"] == res[1]["dp_grad"]
+
+
+def test_single_process_fallbacks():
+    from mixgrpo_amd import dist_utils as DU
+    t = torch.arange(3.0)
+    assert DU.gather_tensor(t) is t
+    assert DU.allreduce_sum_(t.clone()) == []
+    assert DU.world_size() == 1 and DU.rank() == 0
