@@ -63,15 +63,23 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int EPI>
-__global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
+// BIG = false: 128x128 tile, 256 threads (2x2 waves of 64x64).  BIG = true: 256x256 tile, 512 threads (2x4 waves of
+// 128(M) x 64(N)): half the LDS write traffic and 25 % less LDS read traffic per MFMA -- the LDS port, not the MFMA
+// pipe, is what limits the small tile (ds_write_b128 runs at ~79 B/clk/CU).
+template <int EPI, bool BIG>
+__global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
+  constexpr int TM = BIG ? 256 : 128, TN = BIG ? 256 : 128;       // block tile
+  constexpr int NTHR = BIG ? 512 : 256;
+  constexpr int RS = NTHR / 8;                                    // rows covered by one pass of the loader
+  constexpr int TB = TM * 128;                                    // bytes of one operand tile (64 k x 2 B per row)
+  constexpr int STAGE = 2 * TB;
+  constexpr int MT = BIG ? 8 : 4, NTL = 4;                        // 16x16 tiles per wave along M / N
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [buf][A|B][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = BIG ? (wid >> 2) : (wid >> 1), wn = BIG ? (wid & 3) : (wid & 1);
 
   // XCD-aware tile order: consecutive logical tiles (which share A/W panels) go to the same XCD
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -86,18 +94,18 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
   const int in_band = bid - b0 * per_band;
   const int tm = b0 * band + in_band % rows_in_band;
   const int tn = in_band / rows_in_band;
-  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const long m0 = (long)tm * TM, n0 = (long)tn * TN;
 
-  // ---- loader setup: thread owns chunks c = tid + 256*i; row = c>>3 (+32*i), kc = c&7
+  // ---- loader: thread owns 16-byte chunks (row = lrow + RS*i, kc = lkc), i = 0..3; RS*i leaves bits 1..3 of the row
+  // alone, so the swizzle term is the same for all four and one LDS offset (+ RS*128*i) serves them
   const int lrow = tid >> 3, lkc = tid & 7;
-  // rows lrow + 32*i: (row>>1)&7 is the same for all four (32*i leaves bits 1..3 alone), so one LDS offset
   auto a_ptr = [&](int i) {
-    long m = m0 + lrow + 32 * i;
+    long m = m0 + lrow + RS * i;
     if (m >= g.M) m = g.M - 1;
     return g.A + row_off(g.a, m) + lkc * 8;
   };
   auto w_ptr = [&](int i) {
-    long n = n0 + lrow + 32 * i;
+    long n = n0 + lrow + RS * i;
     if (n >= g.N) n = g.N - 1;
     return g.W + n * g.ldw + lkc * 8;
   };
@@ -119,22 +127,22 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
   } while (0)
 #define STORE_TILE(buf)                                                          \
   do {                                                                           \
-    char* base_ = smem + (buf) * 32768 + lds0;                                   \
+    char* base_ = smem + (buf) * STAGE + lds0;                                   \
     *reinterpret_cast<uint4*>(base_) = ra0;                                      \
-    *reinterpret_cast<uint4*>(base_ + 4096) = ra1;                               \
-    *reinterpret_cast<uint4*>(base_ + 8192) = ra2;                               \
-    *reinterpret_cast<uint4*>(base_ + 12288) = ra3;                              \
-    *reinterpret_cast<uint4*>(base_ + 16384) = rw0;                              \
-    *reinterpret_cast<uint4*>(base_ + 16384 + 4096) = rw1;                       \
-    *reinterpret_cast<uint4*>(base_ + 16384 + 8192) = rw2;                       \
-    *reinterpret_cast<uint4*>(base_ + 16384 + 12288) = rw3;                      \
+    *reinterpret_cast<uint4*>(base_ + RS * 128) = ra1;                           \
+    *reinterpret_cast<uint4*>(base_ + 2 * RS * 128) = ra2;                       \
+    *reinterpret_cast<uint4*>(base_ + 3 * RS * 128) = ra3;                       \
+    *reinterpret_cast<uint4*>(base_ + TB) = rw0;                                 \
+    *reinterpret_cast<uint4*>(base_ + TB + RS * 128) = rw1;                      \
+    *reinterpret_cast<uint4*>(base_ + TB + 2 * RS * 128) = rw2;                  \
+    *reinterpret_cast<uint4*>(base_ + TB + 3 * RS * 128) = rw3;                  \
   } while (0)
 
-  f32x4 acc[4][4];  // [n-tile][m-tile]
+  f32x4 acc[NTL][MT];  // [n-tile][m-tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NTL; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nkt = g.K / BK;
@@ -144,38 +152,43 @@ __global__ void __launch_bounds__(NT, 2) gemm_kernel(GemmArgs g) {
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) LOAD_TILE(kt + 1);
-    const char* sa = smem + cur * 32768;
-    const char* sw = sa + 16384;
+    const char* sa = smem + cur * STAGE;
+    const char* sw = sa + TB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[4], fw[4];
+      s16x8 fa[MT], fw[NTL];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ra_ = wm * 64 + t * 16 + fr;
+      for (int t = 0; t < NTL; ++t) {
         const int rw_ = wn * 64 + t * 16 + fr;
-        fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
         fw[t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int t = 0; t < MT; ++t) {
+        const int ra_ = wm * (MT * 16) + t * 16 + fr;
+        fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nkt) STORE_TILE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
+#undef LOAD_TILE
+#undef STORE_TILE
 
   // ---- epilogue: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long m = m0 + wm * 64 + j * 16 + fr;
+  for (int j = 0; j < MT; ++j) {
+    const long m = m0 + wm * (MT * 16) + j * 16 + fr;
     if (m >= g.M) continue;
     const long crow = row_off(g.c, m);
     const long bidx = m / g.c.rpb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NTL; ++i) {
       const long n = n0 + wn * 64 + i * 16 + fq * 4;
       if (n >= g.N) continue;   // N is a multiple of 4 (checked on the host)
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -272,8 +285,17 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
 
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t st) {
-  const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-  gemm_kernel<EPI><<<tiles, NT, 65536, st>>>(g);
+  // the 256x256 tile needs enough tiles to fill 256 CUs; skinny / small problems keep the 128x128 tile
+  const long tiles_big = (long)cdiv(g.M, 256) * cdiv(g.N, 256);
+  const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= 192 && (g.N % 256 == 0 || g.N >= 2048);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_set = true;
+  }
+  if (big) gemm_kernel<EPI, true><<<(int)tiles_big, 512, 131072, st>>>(g);
+  else gemm_kernel<EPI, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -300,15 +322,6 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   g.ldw = ldw;
   g.beta = beta;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void*)gemm_kernel<EPI_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_MULAUX>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
   switch (epilogue) {
     case EPI_BIAS: return launch<EPI_BIAS>(g, st);
     case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU>(g, st);
