@@ -14,6 +14,8 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -66,7 +68,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // BIG = false: 128x128 tile, 256 threads (2x2 waves of 64x64).  BIG = true: 256x256 tile, 512 threads (2x4 waves of
 // 128(M) x 64(N)): half the LDS write traffic and 25 % less LDS read traffic per MFMA -- the LDS port, not the MFMA
 // pipe, is what limits the small tile (ds_write_b128 runs at ~79 B/clk/CU).
-template <int EPI, bool BIG>
+// GLDS = true stages both operands with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write issue):
+// the LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE address.
+template <int EPI, bool BIG, bool GLDS>
 __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = BIG ? 256 : 128, TN = BIG ? 256 : 128;       // block tile
   constexpr int NTHR = BIG ? 512 : 256;
@@ -99,19 +103,33 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
   // ---- loader: thread owns 16-byte chunks (row = lrow + RS*i, kc = lkc), i = 0..3; RS*i leaves bits 1..3 of the row
   // alone, so the swizzle term is the same for all four and one LDS offset (+ RS*128*i) serves them
   const int lrow = tid >> 3, lkc = tid & 7;
+  const int src_kc = GLDS ? swz(lrow, lkc) : lkc;   // GLDS: linear LDS slot lkc of a row holds logical chunk lkc ^ f(row)
   auto a_ptr = [&](int i) {
     long m = m0 + lrow + RS * i;
     if (m >= g.M) m = g.M - 1;
-    return g.A + row_off(g.a, m) + lkc * 8;
+    return g.A + row_off(g.a, m) + src_kc * 8;
   };
   auto w_ptr = [&](int i) {
     long n = n0 + lrow + RS * i;
     if (n >= g.N) n = g.N - 1;
-    return g.W + n * g.ldw + lkc * 8;
+    return g.W + n * g.ldw + src_kc * 8;
   };
   const bf16_raw* ap0 = a_ptr(0); const bf16_raw* ap1 = a_ptr(1); const bf16_raw* ap2 = a_ptr(2); const bf16_raw* ap3 = a_ptr(3);
   const bf16_raw* wp0 = w_ptr(0); const bf16_raw* wp1 = w_ptr(1); const bf16_raw* wp2 = w_ptr(2); const bf16_raw* wp3 = w_ptr(3);
   const int lds0 = lrow * 128 + swz(lrow, lkc) * 16;
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef const __attribute__((address_space(1))) bf16_raw gbl_bf16;
+#define GLDS_ONE(gp, ko, off)                                                                                      \
+  __builtin_amdgcn_global_load_lds((gbl_bf16*)((gp) + (ko)), (lds_char*)(smem + (off)), 16, 0, 0)
+#define GLDS_TILE(kt, buf)                                                                                         \
+  do {                                                                                                             \
+    const long ko = (long)(kt) * BK;                                                                               \
+    const int wb_ = (buf) * STAGE + wid * 1024;   /* wave-uniform LDS base; the DMA adds lane*16 */                \
+    GLDS_ONE(ap0, ko, wb_); GLDS_ONE(ap1, ko, wb_ + RS * 128); GLDS_ONE(ap2, ko, wb_ + 2 * RS * 128);              \
+    GLDS_ONE(ap3, ko, wb_ + 3 * RS * 128);                                                                         \
+    GLDS_ONE(wp0, ko, wb_ + TB); GLDS_ONE(wp1, ko, wb_ + TB + RS * 128); GLDS_ONE(wp2, ko, wb_ + TB + 2 * RS * 128); \
+    GLDS_ONE(wp3, ko, wb_ + TB + 3 * RS * 128);                                                                    \
+  } while (0)
   uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
 #define LOAD_TILE(kt)                                                            \
   do {                                                                           \
@@ -146,12 +164,20 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nkt = g.K / BK;
-  LOAD_TILE(0);
-  STORE_TILE(0);
+  if (GLDS) {
+    GLDS_TILE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    LOAD_TILE(0);
+    STORE_TILE(0);
+  }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) LOAD_TILE(kt + 1);
+    if (kt + 1 < nkt) {
+      if (GLDS) GLDS_TILE(kt + 1, cur ^ 1);
+      else LOAD_TILE(kt + 1);
+    }
     const char* sa = smem + cur * STAGE;
     const char* sw = sa + TB;
 #pragma unroll
@@ -173,12 +199,18 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
         for (int i = 0; i < NTL; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) STORE_TILE(cur ^ 1);
+    if (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (kt + 1 < nkt) {
+      STORE_TILE(cur ^ 1);
+    }
     __syncthreads();
     cur ^= 1;
   }
 #undef LOAD_TILE
 #undef STORE_TILE
+#undef GLDS_TILE
+#undef GLDS_ONE
 
   // ---- epilogue: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
 #pragma unroll
@@ -290,12 +322,15 @@ int launch(const GemmArgs& g, hipStream_t st) {
   const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= 192 && (g.N % 256 == 0 || g.N >= 2048);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  if (big) gemm_kernel<EPI, true><<<(int)tiles_big, 512, 131072, st>>>(g);
-  else gemm_kernel<EPI, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 2;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA
+  if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
+  else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);
+  else gemm_kernel<EPI, false, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -357,13 +357,23 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
   }
 }
 
-__global__ void qk_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ gq, float* __restrict__ gk,
-                                     long nblocks) {
-  const int which = blockIdx.x, c = threadIdx.x;   // 2 blocks x 128 threads
+// sum the per-block partials: one block per (which, 16-column slab); 256 threads = 16 columns x 16 row-lanes
+__global__ void __launch_bounds__(256) qk_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ gq,
+                                                            float* __restrict__ gk, long nblocks) {
+  __shared__ float red[16][17];
+  const int which = blockIdx.x >> 3, c0 = (blockIdx.x & 7) * 16;
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   float s = 0.f;
-  for (long k = 0; k < nblocks; ++k) s += part[(k * 2 + which) * 128 + c];
-  float* dst = which ? gk : gq;
-  dst[c] += s;
+  for (long k = ry; k < nblocks; k += 16) s += part[(k * 2 + which) * 128 + c0 + cx];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cx];
+    float* dst = which ? gk : gq;
+    dst[c0 + cx] += t;
+  }
 }
 
 }  // namespace
@@ -447,7 +457,7 @@ extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* w
   QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ws, H, S, Sp, rows_per_batch, s0};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
-  qk_bwd_finish_kernel<<<2, 128, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);
+  qk_bwd_finish_kernel<<<16, 256, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
