@@ -174,30 +174,49 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) {
-      if (GLDS) GLDS_TILE(kt + 1, cur ^ 1);
-      else LOAD_TILE(kt + 1);
+    if (GLDS) {
+      // unconditional (the last iteration re-fetches the last tile into the idle buffer): keeps the K-loop body one
+      // scheduling region so the ds_read / MFMA interleave below can be pinned
+      GLDS_TILE(kt + 1 < nkt ? kt + 1 : kt, cur ^ 1);
+    } else if (kt + 1 < nkt) {
+      LOAD_TILE(kt + 1);
     }
     const char* sa = smem + cur * STAGE;
     const char* sw = sa + TB;
+    // all fragments of the K-tile are requested up front (both 32-deep k-steps): the second k-step's ds_reads
+    // return underneath the first k-step's MFMAs instead of in an MFMA-idle phase
+    s16x8 fa[2][MT], fw[2][NTL];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[MT], fw[NTL];
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         const int rw_ = wn * 64 + t * 16 + fr;
-        fw[t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
+        fw[ks][t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int ra_ = wm * (MT * 16) + t * 16 + fr;
-        fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
+        fa[ks][t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
       }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int i = 0; i < NTL; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+    }
+    if (GLDS && BIG) {
+      // software pipeline: the fragment reads of MFMA group g+1 are issued before the MFMAs of group g
+      // (group = 8 MFMAs = two 16-row A fragments x the four W fragments); masks: 0x100 DS_READ, 0x8 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int grp = 0; grp < 8; ++grp) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        if (grp == 2) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        else if (grp < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
     }
     if (GLDS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -307,6 +326,57 @@ __global__ void __launch_bounds__(256) transpose_kernel(const bf16_raw* __restri
   }
 }
 
+// Fast path (N % 8 == 0, 16-byte aligned rows): each thread moves an 8x8 block through registers (8 x 16-byte loads,
+// 32 v_perm, 8 x 16-byte stores): no LDS, 128-byte segments on both sides.  Block = 16x16 threads = 128x128 tile.
+__device__ __forceinline__ uint32_t lo16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100); }
+__device__ __forceinline__ uint32_t hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302); }
+__global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restrict__ in, bf16_raw* __restrict__ out,
+                                                         float* __restrict__ part, int M, int N, RowMap im, long ldo) {
+  __shared__ float cs[16][129];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // tx: 8-column group, ty: 8-row group
+  const int n0 = blockIdx.x * 128 + tx * 8;
+  const long m0 = (long)blockIdx.y * 128 + ty * 8;
+  uint32_t r[8][4];
+  float csum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) csum[j] = 0.f;
+  const bool ncol_ok = n0 < N;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long m = m0 + i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ncol_ok && m < M) v = *reinterpret_cast<const uint4*>(in + row_off(im, m) + n0);
+    r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
+    if (part) {
+      csum[0] += bf2f(v.x & 0xffff); csum[1] += bf2f(v.x >> 16); csum[2] += bf2f(v.y & 0xffff); csum[3] += bf2f(v.y >> 16);
+      csum[4] += bf2f(v.z & 0xffff); csum[5] += bf2f(v.z >> 16); csum[6] += bf2f(v.w & 0xffff); csum[7] += bf2f(v.w >> 16);
+    }
+  }
+  // out row (n0 + c) = [in[m0+0][c], in[m0+1][c], ..., in[m0+7][c]]
+  if (ncol_ok && m0 < ldo) {
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {           // column pair (2*c2, 2*c2+1) lives in dword c2 of every row
+      uint4 e, o;
+      e.x = lo16(r[0][c2], r[1][c2]); e.y = lo16(r[2][c2], r[3][c2]); e.z = lo16(r[4][c2], r[5][c2]); e.w = lo16(r[6][c2], r[7][c2]);
+      o.x = hi16(r[0][c2], r[1][c2]); o.y = hi16(r[2][c2], r[3][c2]); o.z = hi16(r[4][c2], r[5][c2]); o.w = hi16(r[6][c2], r[7][c2]);
+      *reinterpret_cast<uint4*>(out + (long)(n0 + 2 * c2) * ldo + m0) = e;
+      *reinterpret_cast<uint4*>(out + (long)(n0 + 2 * c2 + 1) * ldo + m0) = o;
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[ty][tx * 8 + j] = csum[j];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += cs[k][threadIdx.x];
+      const int n = blockIdx.x * 128 + threadIdx.x;
+      if (n < N && (long)blockIdx.y * 128 < M) part[(long)blockIdx.y * N + n] = t;
+    }
+  }
+}
+
 __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N, float beta) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -372,7 +442,7 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   return MGX_ERR_ARG;
 }
 
-extern "C" long mgx_transpose_partial_elems(int M, int N) { return (long)cdiv(M, 64) * N; }
+extern "C" long mgx_transpose_partial_elems(int M, int N) { return (long)cdiv(M, 64) * N; }   // covers both paths
 
 extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* colsum_partial, float* colsum_out,
                                   float colsum_beta, int M, int N, long ld_in, long in_rpb, long in_bstride, long ld_out,
@@ -381,9 +451,17 @@ extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* cols
   MGX_REQUIRE(ld_out >= M, "output leading dimension must cover M");
   MGX_REQUIRE((colsum_partial == nullptr) == (colsum_out == nullptr), "column sums need both workspace and output");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
-  transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
-  if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
+  const bool fast = N % 8 == 0 && ld_in % 8 == 0 && in_bstride % 8 == 0 && ld_out % 8 == 0 &&
+                    ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (fast) {
+    dim3 grid(cdiv(N, 128), cdiv(ld_out, 128));
+    transpose8_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
+    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 128), N, colsum_beta);
+  } else {
+    dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
+    transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
+    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
+  }
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
