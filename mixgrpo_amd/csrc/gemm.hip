@@ -47,6 +47,7 @@ struct GemmArgs {
   RowMap a, c;
   long ldw;
   float beta;             // EPI_F32_ACC: C = beta*C + acc
+  int rowwise_ok;         // all bf16 side operands are 16-byte addressable: the LDS-staged epilogue may be used
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -231,7 +232,83 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
 #undef GLDS_TILE
 #undef GLDS_ONE
 
-  // ---- epilogue: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
+  // ---- epilogue A (256x256 tile, bf16 output): stage the wave's 128x64 sub-tile through LDS and finish it row-wise
+  // with 16-byte loads/stores (one full 128-byte line per 8 lanes): the 8-byte row-per-lane stores of epilogue B are
+  // store-ISSUE bound (17 us per tile = 18 % of a K=3072 GEMM); this form halves the store instructions and moves
+  // the gate / residual / aux traffic to 16-byte accesses too.
+  if (BIG && EPI != EPI_F32_ACC && g.rowwise_ok) {
+    char* reg = smem + wid * 16384;    // [128 rows][64 cols] bf16, 16-byte chunk index XOR (row & 7)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) {
+        const long n = n0 + wn * 64 + i * 16 + fq * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (g.bias && n < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+        }
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        const int c16 = i * 2 + (fq >> 1);
+        *reinterpret_cast<uint2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+      }
+    }
+    // same-wave LDS ops complete in order; no block barrier needed (each wave owns its region)
+    const int rl = lane >> 3, c16 = lane & 7;
+    const long n = n0 + wn * 64 + c16 * 8;
+    long m = m0 + wm * 128 + rl;
+    long bidx = m / g.c.rpb;
+    long rin = m - bidx * g.c.rpb;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + rl;
+      if (m < g.M && n < g.N) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
+        float v[8];
+        v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+        v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
+        bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
+        if (EPI == EPI_BIAS_GELU) {
+          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+        } else if (EPI == EPI_BIAS_GATE_RES) {
+          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
+          const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
+          const uint4 rr = *reinterpret_cast<const uint4*>(cp);
+          const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
+            v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
+          }
+        } else if (EPI == EPI_BIAS_MULAUX) {
+          const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
+          const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
+            v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
+          }
+        }
+        uint4 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(cp) = o;
+      }
+      m += 8;
+      rin += 8;
+      while (rin >= g.c.rpb) { rin -= g.c.rpb; ++bidx; }
+    }
+    return;
+  }
+
+  // ---- epilogue B: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const long m = m0 + wm * (MT * 16) + j * 16 + fr;
@@ -395,10 +472,12 @@ int launch(const GemmArgs& g, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_set = true;
   }
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 2;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA
-  if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
+  if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+  else if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
   else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);
   else gemm_kernel<EPI, false, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   MGX_CHECK_LAUNCH();
@@ -426,6 +505,9 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   g.c = RowMap{ldc, c_rpb, c_bstride};
   g.ldw = ldw;
   g.beta = beta;
+  g.rowwise_ok = (N % 8 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
+                 (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
+                 (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case EPI_BIAS: return launch<EPI_BIAS>(g, st);
