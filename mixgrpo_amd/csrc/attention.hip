@@ -16,12 +16,12 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int HD = 128;
 constexpr int QW = 32;            // queries per wave
-constexpr int NW = 8;             // waves per workgroup
-constexpr int QB = QW * NW;       // 256 queries per workgroup
 constexpr int KB = 64;            // keys per tile
 constexpr int K_TILE_BYTES = KB * HD * 2;   // 16 KiB
 constexpr int V_TILE_BYTES = HD * KB * 2;   // 16 KiB
@@ -47,7 +47,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
 }
 
+// NW waves per workgroup (QB = 32*NW queries).  NW = 4 puts two independent workgroups on a CU (64 KiB LDS each): their
+// barriers are unrelated, so one workgroup's softmax VALU phase runs under the other's MFMA phase instead of the two
+// waves of a SIMD marching in lockstep.
+template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
+  constexpr int QB = QW * NW;
+  constexpr int NCH = 1024 / (NW * 64);   // 16-byte chunks per thread per operand tile
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | Vt tile]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -77,32 +83,35 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   for (int ks = 0; ks < 8; ++ks)
     qf[ks] = *reinterpret_cast<const s16x8*>(Qp + (long)qrow * HD + ks * 16 + h * 8);
 
-  // ---- staging: K tile = 1024 16-B chunks, Vt tile = 1024 16-B chunks; 512 threads -> 2 + 2 each
-  const int kc_key0 = tid >> 4, kc_chunk = tid & 15;          // chunk id = tid (+512): key = id>>4
-  const int vc_d0 = tid >> 3, vc_chunk = tid & 7;             // chunk id = tid (+512): d = id>>3, 16-B chunk of 64 keys
-  uint4 sk0, sk1, sv0, sv1;
+  // ---- staging: K tile = 1024 16-B chunks, Vt tile = 1024 16-B chunks; NCH of each per thread
+  const int kc_key0 = tid >> 4, kc_chunk = tid & 15;          // chunk id = tid + NW*64*i: key = id>>4
+  const int vc_d0 = tid >> 3, vc_chunk = tid & 7;             // chunk id = tid + NW*64*i: d = id>>3, 16-B chunk of 64 keys
+  constexpr int KSTEP = NW * 4, DSTEP = NW * 8;               // keys / d rows advanced per pass
+  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;   // named (not an array): keeps the staging registers out of scratch
   const int ntiles = (g.S + KB - 1) / KB;
+#define LOAD1(i_, SK, SV)                                                                           \
+  if constexpr (NCH > i_) {                                                                         \
+    int ka = key_base + kc_key0 + KSTEP * i_;                                                       \
+    if (ka >= g.S) ka = g.S - 1;                                                                    \
+    SK = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                        \
+    SV = *reinterpret_cast<const uint4*>(Vp + (long)(vc_d0 + DSTEP * i_) * g.Sp + key_base + vc_chunk * 8); \
+  }
 #define LOAD_KV(t)                                                                                  \
   do {                                                                                              \
     const int key_base = (t) * KB;                                                                  \
-    int ka = key_base + kc_key0, kb_ = key_base + kc_key0 + 32;                                     \
-    if (ka >= g.S) ka = g.S - 1;                                                                    \
-    if (kb_ >= g.S) kb_ = g.S - 1;                                                                  \
-    sk0 = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                       \
-    sk1 = *reinterpret_cast<const uint4*>(Kp + (long)kb_ * HD + kc_chunk * 8);                      \
-    sv0 = *reinterpret_cast<const uint4*>(Vp + (long)vc_d0 * g.Sp + key_base + vc_chunk * 8);        \
-    sv1 = *reinterpret_cast<const uint4*>(Vp + (long)(vc_d0 + 64) * g.Sp + key_base + vc_chunk * 8); \
+    LOAD1(0, sk0, sv0) LOAD1(1, sk1, sv1) LOAD1(2, sk2, sv2) LOAD1(3, sk3, sv3)                     \
   } while (0)
+#define STORE1(i_, SK, SV)                                                                          \
+  if constexpr (NCH > i_) {                                                                         \
+    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0 + KSTEP * i_, kc_chunk)) = SK;                 \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk)) = make_uint2(SV.x, SV.y); \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk + 1)) = make_uint2(SV.z, SV.w); \
+  }
 #define STORE_KV(buf)                                                                               \
   do {                                                                                              \
     char* kb_ptr = smem + (buf) * (K_TILE_BYTES + V_TILE_BYTES);                                    \
     char* vb_ptr = kb_ptr + K_TILE_BYTES;                                                           \
-    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0, kc_chunk)) = sk0;                             \
-    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0 + 32, kc_chunk)) = sk1;                        \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0, 2 * vc_chunk)) = make_uint2(sv0.x, sv0.y);      \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0, 2 * vc_chunk + 1)) = make_uint2(sv0.z, sv0.w);  \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + 64, 2 * vc_chunk)) = make_uint2(sv1.x, sv1.y); \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + 64, 2 * vc_chunk + 1)) = make_uint2(sv1.z, sv1.w); \
+    STORE1(0, sk0, sv0) STORE1(1, sk1, sv1) STORE1(2, sk2, sv2) STORE1(3, sk3, sv3)                 \
   } while (0)
 
   f32x16 o[4];   // O^T tiles: d in [32*dt, 32*dt+32), column = query r
@@ -234,13 +243,12 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   g.Q = Q; g.K = K; g.Vt = Vt; g.O = O; g.lse = lse;
   g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
   g.scale_log2e = scale * 1.4426950408889634f;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr = true;
+  static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 4;
+  if (nw == 8) {
+    attn_fwd_kernel<8><<<cdiv(S, 256) * H * B, 512, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
+  } else {
+    attn_fwd_kernel<4><<<cdiv(S, 128) * H * B, 256, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
   }
-  const int nq = cdiv(S, QB);
-  attn_fwd_kernel<<<nq * H * B, NW * 64, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
