@@ -462,6 +462,269 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
   out[n] = beta * out[n] + s;
 }
 
+// ------------------------------------------------------------------------------------------ persistent variant
+// One workgroup per CU walks a strided list of 256x256 tiles.  The first K-tile of the NEXT tile is DMA'd into the
+// idle LDS buffer during the last K-step of the current one (no exposed prologue, no dispatch gap between tiles), the
+// epilogue stages through the buffer that was just consumed (two 64-row passes per wave: 64 KiB), and its global
+// stores drain underneath the next tile's K-loop.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
+  constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, STAGE = 2 * TB, MT = 8, NTL = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
+  const int nwg = tiles_m * tiles_n;
+  const int nkt = g.K / BK;
+  // tile list of this workgroup: the XCD (blockIdx & 7) owns a contiguous range of the banded tile order and its
+  // workgroups take every (gridDim/8)-th tile of it
+  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
+  const int q = nwg >> 3, rem = nwg & 7;
+  const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int xend = xbeg + (xcd < rem ? q + 1 : q);
+  int t_lin = xbeg + lane_in_xcd;
+  if (t_lin >= xend) return;
+
+  const int lrow = tid >> 3, lkc = tid & 7;
+  const int src_kc = swz(lrow, lkc);
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef const __attribute__((address_space(1))) bf16_raw gbl_bf16;
+  const bf16_raw *ap0, *ap1, *ap2, *ap3, *wp0, *wp1, *wp2, *wp3;
+  long m0, n0;
+#define TILE_COORDS(tl, M0, N0)                                            \
+  do {                                                                     \
+    const int band = 8, per_band = band * tiles_n;                         \
+    const int b0 = (tl) / per_band;                                        \
+    const int rows_in_band = min(band, tiles_m - b0 * band);               \
+    const int in_band = (tl) - b0 * per_band;                              \
+    M0 = (long)(b0 * band + in_band % rows_in_band) * TM;                  \
+    N0 = (long)(in_band / rows_in_band) * TN;                              \
+  } while (0)
+#define TILE_PTRS(M0, N0, A0, A1, A2, A3, W0, W1, W2, W3)                                  \
+  do {                                                                                     \
+    long mm, nn;                                                                           \
+    mm = M0 + lrow;          if (mm >= g.M) mm = g.M - 1; A0 = g.A + row_off(g.a, mm) + src_kc * 8; \
+    mm = M0 + lrow + RS;     if (mm >= g.M) mm = g.M - 1; A1 = g.A + row_off(g.a, mm) + src_kc * 8; \
+    mm = M0 + lrow + 2 * RS; if (mm >= g.M) mm = g.M - 1; A2 = g.A + row_off(g.a, mm) + src_kc * 8; \
+    mm = M0 + lrow + 3 * RS; if (mm >= g.M) mm = g.M - 1; A3 = g.A + row_off(g.a, mm) + src_kc * 8; \
+    nn = N0 + lrow;          if (nn >= g.N) nn = g.N - 1; W0 = g.W + nn * g.ldw + src_kc * 8; \
+    nn = N0 + lrow + RS;     if (nn >= g.N) nn = g.N - 1; W1 = g.W + nn * g.ldw + src_kc * 8; \
+    nn = N0 + lrow + 2 * RS; if (nn >= g.N) nn = g.N - 1; W2 = g.W + nn * g.ldw + src_kc * 8; \
+    nn = N0 + lrow + 3 * RS; if (nn >= g.N) nn = g.N - 1; W3 = g.W + nn * g.ldw + src_kc * 8; \
+  } while (0)
+#define PGLDS_ONE(gp, ko, off) \
+  __builtin_amdgcn_global_load_lds((gbl_bf16*)((gp) + (ko)), (lds_char*)(smem + (off)), 16, 0, 0)
+#define PGLDS_TILE(A0, A1, A2, A3, W0, W1, W2, W3, kt, buf)                                                   \
+  do {                                                                                                        \
+    const long ko = (long)(kt) * BK;                                                                          \
+    const int wb_ = (buf) * STAGE + wid * 1024;                                                               \
+    PGLDS_ONE(A0, ko, wb_); PGLDS_ONE(A1, ko, wb_ + RS * 128); PGLDS_ONE(A2, ko, wb_ + 2 * RS * 128);         \
+    PGLDS_ONE(A3, ko, wb_ + 3 * RS * 128);                                                                    \
+    PGLDS_ONE(W0, ko, wb_ + TB); PGLDS_ONE(W1, ko, wb_ + TB + RS * 128); PGLDS_ONE(W2, ko, wb_ + TB + 2 * RS * 128); \
+    PGLDS_ONE(W3, ko, wb_ + TB + 3 * RS * 128);                                                               \
+  } while (0)
+
+  TILE_COORDS(t_lin, m0, n0);
+  TILE_PTRS(m0, n0, ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3);
+  PGLDS_TILE(ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (true) {
+    const int t_next = t_lin + per_xcd_wg;
+    const bool has_next = t_next < xend;
+    long nm0 = 0, nn0 = 0;
+    const bf16_raw *nap0 = ap0, *nap1 = ap1, *nap2 = ap2, *nap3 = ap3, *nwp0 = wp0, *nwp1 = wp1, *nwp2 = wp2, *nwp3 = wp3;
+    if (has_next) {
+      TILE_COORDS(t_next, nm0, nn0);
+      TILE_PTRS(nm0, nn0, nap0, nap1, nap2, nap3, nwp0, nwp1, nwp2, nwp3);
+    }
+    f32x4 acc[NTL][MT];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) PGLDS_TILE(ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3, kt + 1, cur ^ 1);
+      else if (has_next) PGLDS_TILE(nap0, nap1, nap2, nap3, nwp0, nwp1, nwp2, nwp3, 0, cur ^ 1);
+      const char* sa = smem + cur * STAGE;
+      const char* sw = sa + TB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s16x8 fa[MT], fw[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          const int rw_ = wn * 64 + t * 16 + fr;
+          fw[t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int ra_ = wm * 128 + t * 16 + fr;
+          fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+          for (int i = 0; i < NTL; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    // ---------------- epilogue of tile (m0, n0); staging buffer = the stage just consumed (cur ^ 1)
+    if (EPI == EPI_F32_ACC || !g.rowwise_ok) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const long m = m0 + wm * 128 + j * 16 + fr;
+        if (m >= g.M) continue;
+        const long crow = row_off(g.c, m);
+        const long bidx = m / g.c.rpb;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+          const long n = n0 + wn * 64 + i * 16 + fq * 4;
+          if (n >= g.N) continue;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (EPI == EPI_F32_ACC) {
+            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + crow + n);
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (g.beta != 0.f) {
+              const float4 old = *cp;
+              o.x += g.beta * old.x; o.y += g.beta * old.y; o.z += g.beta * old.z; o.w += g.beta * old.w;
+            }
+            *cp = o;
+            continue;
+          }
+          if (g.bias) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+            v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+          bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + n;
+          uint2 pre;
+          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          if (EPI == EPI_BIAS_GELU) {
+            if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+          } else if (EPI == EPI_BIAS_GATE_RES) {
+            if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
+            const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
+            const uint2 rr = *reinterpret_cast<const uint2*>(cp);
+            v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
+            v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
+            v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
+            v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
+          } else if (EPI == EPI_BIAS_MULAUX) {
+            const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + n);
+            v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
+            v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
+          }
+          uint2 o;
+          o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(cp) = o;
+        }
+      }
+    } else {
+      char* reg = smem + (cur ^ 1) * STAGE + wid * 8192;    // [64 rows][64 cols] bf16 per pass, chunk XOR (row & 7)
+      const int rl = lane >> 3, c16 = lane & 7;
+      const long n = n0 + wn * 64 + c16 * 8;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = half * 4 + jj;
+          const int row = jj * 16 + fr;
+#pragma unroll
+          for (int i = 0; i < NTL; ++i) {
+            const long nb = n0 + wn * 64 + i * 16 + fq * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.bias && nb < g.N) {
+              const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + nb);
+              v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+            }
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            const int cc = i * 2 + (fq >> 1);
+            *reinterpret_cast<uint2*>(reg + row * 128 + ((cc ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+          }
+        }
+        long m = m0 + wm * 128 + half * 64 + rl;
+        long bidx = m / g.c.rpb;
+        long rin = m - bidx * g.c.rpb;
+        // all 8 row reads of the pass are requested before any is consumed
+        uint4 u[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rl;
+          u[it] = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          if (m < g.M && n < g.N) {
+            bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
+            if (EPI == EPI_BIAS) {
+              *reinterpret_cast<uint4*>(cp) = u[it];
+            } else {
+              float v[8];
+              v[0] = bf2f(u[it].x & 0xffff); v[1] = bf2f(u[it].x >> 16); v[2] = bf2f(u[it].y & 0xffff); v[3] = bf2f(u[it].y >> 16);
+              v[4] = bf2f(u[it].z & 0xffff); v[5] = bf2f(u[it].z >> 16); v[6] = bf2f(u[it].w & 0xffff); v[7] = bf2f(u[it].w >> 16);
+              if (EPI == EPI_BIAS_GELU) {
+                if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u[it];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+              } else if (EPI == EPI_BIAS_GATE_RES) {
+                if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u[it];
+                const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
+                const uint4 rr = *reinterpret_cast<const uint4*>(cp);
+                const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
+                  v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
+                }
+              } else if (EPI == EPI_BIAS_MULAUX) {
+                const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
+                const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
+                  v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
+                }
+              }
+              uint4 o;
+              o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+              o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+              o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+              o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+              *reinterpret_cast<uint4*>(cp) = o;
+            }
+          }
+          m += 8;
+          rin += 8;
+          if (rin >= g.c.rpb) { bidx = m / g.c.rpb; rin = m - bidx * g.c.rpb; }
+        }
+      }
+    }
+    if (!has_next) break;
+    // the next tile's first DMA (issued at kt = 0 of its K-loop) targets the staging buffer: all waves must be done
+    __syncthreads();
+    t_lin = t_next;
+    m0 = nm0; n0 = nn0;
+    ap0 = nap0; ap1 = nap1; ap2 = nap2; ap3 = nap3; wp0 = nwp0; wp1 = nwp1; wp2 = nwp2; wp3 = nwp3;
+  }
+#undef TILE_COORDS
+#undef TILE_PTRS
+#undef PGLDS_ONE
+#undef PGLDS_TILE
+}
+
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t st) {
   // the 256x256 tile needs enough tiles to fill 256 CUs; skinny / small problems keep the 128x128 tile
@@ -473,10 +736,15 @@ int launch(const GemmArgs& g, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 2;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA
-  if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 4;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA, 4: persistent
+  if (big && mode == 4) {
+    int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
+    if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
+    gemm_persist_kernel<EPI><<<grid, 512, 131072, st>>>(g);
+  } else if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   else if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
   else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);
   else gemm_kernel<EPI, false, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
