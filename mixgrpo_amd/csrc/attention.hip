@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -44,7 +45,10 @@ __device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((
 __device__ __forceinline__ int v_off(int d, int chunk8) { return d * 128 + ((chunk8 ^ ((d >> 1) & 15)) << 3); }
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));   // one v_cvt_pk_bf16_f32
 }
 
 // NW waves per workgroup (QB = 32*NW queries).  NW = 4 puts two independent workgroups on a CU (64 KiB LDS each): their
@@ -125,8 +129,15 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   LOAD_KV(0);
   STORE_KV(0);
   __syncthreads();
+  // make the Q-fragment loads provably complete before the loop: otherwise hipcc's waitcnt pass carries them as
+  // pending into the loop and fences every S^T MFMA behind the (slow) K/V staging loads of the same iteration
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]));
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  // one K/V tile: S^T, online softmax, O^T accumulation.  Kept as a lambda over a compile-time MASK so the full
+  // tiles carry no masking selects (hipcc if-converts a runtime "last tile" test into ~200 v_cndmask per tile).
+  auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     if (t + 1 < ntiles) LOAD_KV(t + 1);
     const char* ks_ = smem + cur * (K_TILE_BYTES + V_TILE_BYTES);
     const char* vs_ = ks_ + K_TILE_BYTES;
@@ -143,9 +154,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
       }
     }
-    // ---- mask keys beyond S (last tile only)
-    const int key_base = t * KB;
-    if (key_base + KB > g.S) {
+    // ---- mask keys beyond S (only the ragged last tile is compiled with MASK)
+    if (MASK) {
+      const int key_base = t * KB;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * g.scale_log2e);   // m_run = -inf on the first tile -> 0
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * g.scale_log2e);   // m_run = -inf on the first tile -> 0
     const float mc = m_new * g.scale_log2e;
     m_run = m_new;
     float psum = 0.f;
@@ -171,8 +182,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const float p0 = exp2f(s[kb][i] * g.scale_log2e - mc);
-        const float p1 = exp2f(s[kb][i + 1] * g.scale_log2e - mc);
+        const float p0 = __builtin_amdgcn_exp2f(s[kb][i] * g.scale_log2e - mc);
+        const float p1 = __builtin_amdgcn_exp2f(s[kb][i + 1] * g.scale_log2e - mc);
         psum += p0 + p1;
         pb[kb][i >> 1] = pack_bf16(p0, p1);
       }
@@ -206,7 +217,10 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
     if (t + 1 < ntiles) STORE_KV(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  const int nfull = g.S / KB;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntiles) tile(nfull, std::true_type{});
 
   // ---- finalize: row sum across the two half-waves, normalise, store O[q][h*128 + d]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

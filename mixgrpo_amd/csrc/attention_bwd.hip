@@ -18,7 +18,10 @@ namespace {
 constexpr int HD = 128;
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));   // one v_cvt_pk_bf16_f32
 }
 // row-major [rows][128] bf16 image, 16-byte chunk swizzle
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
@@ -160,6 +163,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   DKV_LOAD(0);
   DKV_STORE(0);
   __syncthreads();
+  // see attention.hip: make the pre-loop fragment loads provably complete so the loop's MFMAs are not fenced behind
+  // the staging loads
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
   int cur = 0;
   for (int t = 0; t < nqt; ++t) {
     if (t + 1 < nqt) DKV_LOAD(t + 1);
@@ -181,8 +188,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
       const int qa = (i & 3) + 8 * (i >> 2) + 4 * h, qb = qa + 1;
-      float p0 = exp2f(s[i] * g.scale_log2e - lse2[qa]);       // rows beyond S carry lse = +inf -> P = 0
-      float p1 = exp2f(s[i + 1] * g.scale_log2e - lse2[qb]);
+      float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e - lse2[qa]);       // rows beyond S carry lse = +inf -> P = 0
+      float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e - lse2[qb]);
       if (!key_valid) p0 = p1 = 0.f;
       const float d0 = p0 * (dp[i] - dlt[qa]) * g.scale;
       const float d1 = p1 * (dp[i + 1] - dlt[qb]) * g.scale;
@@ -297,6 +304,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
   DQ_LOAD(0);
   DQ_STORE(0);
   __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
+  asm volatile("" :: "v"(lse2), "v"(dlt));
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) DQ_LOAD(t + 1);
@@ -318,8 +328,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         const int k0 = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        float p0 = exp2f(s[i] * g.scale_log2e - lse2);
-        float p1 = exp2f(s[i + 1] * g.scale_log2e - lse2);
+        float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e - lse2);
+        float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e - lse2);
         if (k0 >= g.S) p0 = 0.f;
         if (k0 + 1 >= g.S) p1 = 0.f;
         dsb[i >> 1] = pack_bf16(p0 * (dp[i] - dlt) * g.scale, p1 * (dp[i + 1] - dlt) * g.scale);
