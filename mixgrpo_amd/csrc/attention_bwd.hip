@@ -13,6 +13,8 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int HD = 128;
@@ -168,7 +170,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
   int cur = 0;
-  for (int t = 0; t < nqt; ++t) {
+  auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     if (t + 1 < nqt) DKV_LOAD(t + 1);
     const char* base = smem + cur * DKV_STAGE;
     const float* lse2 = reinterpret_cast<const float*>(base + 32768);
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
       const int qa = (i & 3) + 8 * (i >> 2) + 4 * h, qb = qa + 1;
       float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e - lse2[qa]);       // rows beyond S carry lse = +inf -> P = 0
       float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e - lse2[qb]);
-      if (!key_valid) p0 = p1 = 0.f;
+      if (MASK && !key_valid) p0 = p1 = 0.f;
       const float d0 = p0 * (dp[i] - dlt[qa]) * g.scale;
       const float d1 = p1 * (dp[i + 1] - dlt[qb]) * g.scale;
       pb[i >> 1] = pack_bf16(p0, p1);
@@ -217,6 +220,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
     if (t + 1 < nqt) DKV_STORE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  };
+  if (key0 + 32 > g.S) {          // wave-uniform: only the ragged last key block carries the per-key mask
+    for (int t = 0; t < nqt; ++t) tile(t, std::true_type{});
+  } else {
+    for (int t = 0; t < nqt; ++t) tile(t, std::false_type{});
   }
   const int key = key0 + r;
   if (key < g.S) {
@@ -308,7 +316,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
   for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]), "v"(dof[ks]));
   asm volatile("" :: "v"(lse2), "v"(dlt));
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     if (t + 1 < ntiles) DQ_LOAD(t + 1);
     const char* base = smem + cur * DQ_STAGE;
     const int key_base = t * 64;
@@ -330,8 +339,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
         const int k0 = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e - lse2);
         float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e - lse2);
-        if (k0 >= g.S) p0 = 0.f;
-        if (k0 + 1 >= g.S) p1 = 0.f;
+        if (MASK) {
+          if (k0 >= g.S) p0 = 0.f;
+          if (k0 + 1 >= g.S) p1 = 0.f;
+        }
         dsb[i >> 1] = pack_bf16(p0 * (dp[i] - dlt) * g.scale, p1 * (dp[i + 1] - dlt) * g.scale);
       }
 #pragma unroll
@@ -351,7 +362,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
     if (t + 1 < ntiles) DQ_STORE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  const int nfull = g.S / 64;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntiles) tile(nfull, std::true_type{});
   if (q_valid) {
     bf16_raw* dqp = g.dQ + (bhS + q0 + r) * HD;
 #pragma unroll

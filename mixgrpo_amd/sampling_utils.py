@@ -385,13 +385,18 @@ def flash_schedule(sigma_schedule, determistic, ratio, shift):
 
 
 def run_sample_step(args, z, progress_bar, sigma_schedule, transformer, encoder_hidden_states, pooled_prompt_embeds,
-                    text_ids, image_ids, grpo_sample, determistic, noises=None):
+                    text_ids, image_ids, grpo_sample, determistic, noises=None, shared_rows=False):
     """T-step mixed ODE/SDE rollout (reference sampling_utils.py:12-155).
 
     Returns (z, latents, all_latents [B,T'+1,N,C] fp32, all_log_probs [B,T'] fp32).  `all_latents` is a
     transposed view of a step-major buffer [T'+1,B,N,C] (each solver step writes its output in place, and the
     training replay reads whole steps contiguously).  `noises` (optional) injects pre-drawn noise for parity
     tests, consumed in the reference's RNG order.
+
+    `shared_rows=True` declares that all batch rows start identical (same x_T, same prompt: the reference's
+    `init_same_noise` group).  Until the first step that injects per-sample noise the rows stay bit-identical, so
+    the model and the solver run ONCE (batch 1) for those steps and the result is broadcast -- the reference
+    recomputes the same values G times.  Outputs are unchanged.
     """
     dev = z.device
     noises = iter(noises) if noises is not None else None
@@ -413,22 +418,48 @@ def run_sample_step(args, z, progress_bar, sigma_schedule, transformer, encoder_
     txt_ids = text_ids.repeat(encoder_hidden_states.shape[1], 1)
     x0 = None
     n_run = 0
+    # index of the first step whose update depends on per-sample noise (rows diverge AFTER that step's forward)
+    first_noisy = steps
+    if shared_rows and B > 1:
+        for j in range(steps):
+            in_flow = (not use_dpm) or (post and j <= last_sde)
+            if (in_flow or not post) and not determistic[j]:
+                first_noisy = j
+                break
+    else:
+        first_noisy = -1
+    ehs_all, pooled_all = encoder_hidden_states, pooled_prompt_embeds
     for i in progress_bar:
+        one = shared_rows and B > 1 and i <= first_noisy       # forward at batch 1
+        solve_one = shared_rows and B > 1 and i < first_noisy    # solver step at batch 1 too
+        encoder_hidden_states = ehs_all[:1] if one else ehs_all
+        pooled_prompt_embeds = pooled_all[:1] if one else pooled_all
         timestep_value = int(sig[i] * 1000)
         # int(sigma*1000)/1000 formed on the host as an IEEE fp32 division (reference :64-71 divides a long
         # tensor by 1000 on the device, where eager mode multiplies by the reciprocal instead)
-        timestep = torch.full([B], float(np.float32(timestep_value) / np.float32(1000)), device=dev, dtype=_F32)
+        timestep = torch.full([1 if one else B], float(np.float32(timestep_value) / np.float32(1000)), device=dev,
+                              dtype=_F32)
         transformer.eval()
         with torch.autocast("cuda", torch.bfloat16):
-            pred = transformer(hidden_states=z, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
-                               guidance=guidance, txt_ids=txt_ids, pooled_projections=pooled_prompt_embeds,
-                               img_ids=image_ids, joint_attention_kwargs=None, return_dict=False)[0]
-        zf = buf[i] if i > 0 else buf[0]
+            pred = transformer(hidden_states=z[:1] if one else z, encoder_hidden_states=encoder_hidden_states,
+                               timestep=timestep, guidance=guidance, txt_ids=txt_ids,
+                               pooled_projections=pooled_prompt_embeds, img_ids=image_ids, joint_attention_kwargs=None,
+                               return_dict=False)[0]
+        if one and not solve_one:
+            pred = pred.expand(B, -1, -1).contiguous()          # rows diverge in this step's update
+            if state is not None:
+                state.model_outputs = [None if m is None else m.expand(B, -1, -1).contiguous()
+                                       for m in state.model_outputs]
+        zf = buf[i]
         nxt = buf[i + 1]
+        if solve_one:
+            zf, nxt = zf[:1], nxt[:1]
         keep_x0 = args.drop_last_sample and i == steps - 1
         if (not use_dpm) or (post and i <= last_sde):
             if args.flow_grpo_sampling:
                 nz = next(noises) if noises is not None else None
+                if nz is not None and solve_one:
+                    nz = nz[:1]
                 _, x0_i, lp, _, _ = flow_grpo_step(pred, zf, args.eta, sig, i, None, determistic=determistic[i],
                                                    noise=nz, prev_out=nxt, want_x0=keep_x0 or post, want_mean=False)
                 if post:  # feed the multistep history inside/before the window (reference :116-127)
@@ -446,6 +477,12 @@ def run_sample_step(args, z, progress_bar, sigma_schedule, transformer, encoder_
             _, x0_i, lp = dpm_step(args, pred, zf, i, sig[:-1], sig, dpm_state=state,
                                    generator=None if nz is not None else torch.Generator(device=dev),
                                    variance_noise=nz, sde_solver=sde, x_out=nxt)
+        if solve_one:                                            # broadcast the shared result to all rows
+            buf[i + 1][1:].copy_(nxt.expand(B - 1, -1, -1))
+            nxt = buf[i + 1]
+            lp = lp.expand(B)
+            if x0_i is not None:
+                x0_i = x0_i.expand(B, -1, -1)
         x0 = x0_i
         z = nxt
         logps[i].copy_(lp)

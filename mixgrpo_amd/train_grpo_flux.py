@@ -121,6 +121,9 @@ def sample_reference_model(args, device, transformer, vae, encoder_hidden_states
         raise ValueError(f"training_strategy {args.training_strategy} is not supported.")
     image_ids = prepare_latent_image_ids(1, lh // 2, lw // 2, device, BF16)
     rb = args.rollout_batch if getattr(args, "rollout_batch", 0) else B
+    # one prompt per rank and a shared x_T: the group's rows are identical until the first SDE step
+    shared = bool(args.init_same_noise and getattr(args, "use_group", False) and B == args.num_generations
+                  and getattr(args, "share_rollout_prefix", True))
     lat_chunks, lp_chunks, final_chunks = [], [], []
     for b0 in range(0, B, rb):
         nb = min(rb, B - b0)
@@ -132,7 +135,8 @@ def sample_reference_model(args, device, transformer, vae, encoder_hidden_states
                                                      encoder_hidden_states[b0:b0 + nb],
                                                      pooled_prompt_embeds[b0:b0 + nb], text_ids[b0:b0 + 1], image_ids,
                                                      True, det,
-                                                     noises=[n[b0:b0 + nb].to(device) for n in inj["steps"]] if inj else None)
+                                                     noises=[n[b0:b0 + nb].to(device) for n in inj["steps"]] if inj else None,
+                                                     shared_rows=shared)
         lat_chunks.append(bl)
         lp_chunks.append(blp)
         final_chunks.append(latents)

@@ -221,3 +221,35 @@ def test_full_size_properties():
     assert torch.equal(L.unpack_latents(packed, 1024, 1024, 8), lat)
     ref_pack = lat.view(8, 16, 64, 2, 64, 2).permute(0, 2, 4, 1, 3, 5).reshape(8, 4096, 64)
     assert torch.equal(packed, ref_pack)
+
+
+@pytest.mark.parametrize("window,kw", [([3, 4], {}), ([0, 1], {}), ([2, 3], dict(flow_grpo_sampling=False, eta=0.3)),
+                                       ([1, 2], dict(dpm_algorithm_type="dpmsolver++", dpm_apply_strategy="post",
+                                                     dpm_post_compress_ratio=0.5, dpm_solver_order=2,
+                                                     dpm_solver_type="midpoint"))])
+def test_shared_prefix_rollout_is_bit_identical(window, kw):
+    """Group rows that start identical: running the pre-window steps once (batch 1) and broadcasting must give exactly
+    the rollout of the full batch."""
+    from mixgrpo_amd import sampling_utils as SU
+    base = dict(dpm_algorithm_type="null", dpm_apply_strategy="post", dpm_post_compress_ratio=0.4, dpm_solver_order=2,
+                dpm_solver_type="midpoint", sample_strategy="progressive", shift=3.0, flow_grpo_sampling=True, eta=0.7,
+                drop_last_sample=False)
+    base.update(kw)
+    a = Namespace(**base)
+    T, B = 8, 4
+    sig = SU.sd3_time_shift(a.shift, torch.linspace(1, 0, T + 1))
+    det = [i not in window for i in range(T)]
+    z0 = R_["in/z0"].repeat(B, 1, 1)
+    ehs, pooled = R_["in/ehs"].repeat(B, 1, 1), R_["in/pooled"].repeat(B, 1)
+    g = torch.Generator().manual_seed(3)
+    ndt = torch.bfloat16 if a.flow_grpo_sampling else torch.float32
+    noises = [torch.randn(z0.shape, generator=g).to(ndt) for _ in range(T)]
+    m = ElementwiseToy().cuda()
+    outs = []
+    for shared in (False, True):
+        with torch.no_grad():
+            outs.append(SU.run_sample_step(a, dev(z0), range(T), sig, m, dev(ehs), dev(pooled), dev(R_["in/text_ids"]),
+                                           dev(R_["in/img_ids"]), True, det, noises=[dev(n) for n in noises],
+                                           shared_rows=shared))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(torch.nan_to_num(x.contiguous(), nan=7.0), torch.nan_to_num(y.contiguous(), nan=7.0))
