@@ -66,6 +66,153 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Shared epilogue of the one-tile-per-workgroup kernels.  `BIGT`: 256x256 tile (wave sub-tile 128x64, MT = 8) whose
+// bf16 results may be staged through the (now idle) LDS and written row-wise.
+template <int EPI, bool BIG, int MT, int NTL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NTL][MT], char* smem, int wid, int lane,
+                                              long m0, long n0, int wm, int wn) {
+  const int fr = lane & 15, fq = lane >> 4;
+  // ---- epilogue A (256x256 tile, bf16 output): stage the wave's 128x64 sub-tile through LDS and finish it row-wise
+  // with 16-byte loads/stores (one full 128-byte line per 8 lanes): the 8-byte row-per-lane stores of epilogue B are
+  // store-ISSUE bound (17 us per tile = 18 % of a K=3072 GEMM); this form halves the store instructions and moves
+  // the gate / residual / aux traffic to 16-byte accesses too.
+  if (BIG && EPI != EPI_F32_ACC && g.rowwise_ok) {
+    char* reg = smem + wid * 16384;    // [128 rows][64 cols] bf16, 16-byte chunk index XOR (row & 7)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) {
+        const long n = n0 + wn * 64 + i * 16 + fq * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (g.bias && n < g.N) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+        }
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        const int c16 = i * 2 + (fq >> 1);
+        *reinterpret_cast<uint2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+      }
+    }
+    // same-wave LDS ops complete in order; no block barrier needed (each wave owns its region)
+    const int rl = lane >> 3, c16 = lane & 7;
+    const long n = n0 + wn * 64 + c16 * 8;
+    long m = m0 + wm * 128 + rl;
+    long bidx = m / g.c.rpb;
+    long rin = m - bidx * g.c.rpb;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + rl;
+      if (m < g.M && n < g.N) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
+        float v[8];
+        v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+        v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
+        bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
+        if (EPI == EPI_BIAS_GELU) {
+          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+        } else if (EPI == EPI_BIAS_GATE_RES) {
+          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
+          const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
+          const uint4 rr = *reinterpret_cast<const uint4*>(cp);
+          const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
+            v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
+          }
+        } else if (EPI == EPI_BIAS_MULAUX) {
+          const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
+          const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
+            v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
+          }
+        }
+        uint4 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(cp) = o;
+      }
+      m += 8;
+      rin += 8;
+      while (rin >= g.c.rpb) { rin -= g.c.rpb; ++bidx; }
+    }
+    return;
+  }
+
+  // ---- epilogue B: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const long m = m0 + wm * (MT * 16) + j * 16 + fr;
+    if (m >= g.M) continue;
+    const long crow = row_off(g.c, m);
+    const long bidx = m / g.c.rpb;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+      const long n = n0 + wn * 64 + i * 16 + fq * 4;
+      if (n >= g.N) continue;   // N is a multiple of 4 (checked on the host)
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (EPI == EPI_F32_ACC) {
+        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + crow + n);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.beta != 0.f) {
+          const float4 old = *cp;
+          o.x += g.beta * old.x; o.y += g.beta * old.y; o.z += g.beta * old.z; o.w += g.beta * old.w;
+        }
+        *cp = o;
+        continue;
+      }
+      if (g.bias) {
+        const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the Linear's bf16 output
+      bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + n;
+      if (EPI == EPI_BIAS_GELU) {
+        if (g.aux) {  // keep the pre-activation for the backward pass
+          uint2 pre;
+          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+      } else if (EPI == EPI_BIAS_GATE_RES) {
+        if (g.aux) {  // pre-gate branch output, needed for d(gate)
+          uint2 pre;
+          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
+        }
+        const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
+        const uint2 rr = *reinterpret_cast<const uint2*>(cp);
+        v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
+        v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
+        v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
+        v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
+      } else if (EPI == EPI_BIAS_MULAUX) {
+        // dgrad through GELU: C = (A@W^T) * gelu'(aux)   (aux = saved pre-activation)
+        const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + n);
+        v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
+        v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
+      }
+      uint2 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *reinterpret_cast<uint2*>(cp) = o;
+    }
+  }
+}
+
 // BIG = false: 128x128 tile, 256 threads (2x2 waves of 64x64).  BIG = true: 256x256 tile, 512 threads (2x4 waves of
 // 128(M) x 64(N)): half the LDS write traffic and 25 % less LDS read traffic per MFMA -- the LDS port, not the MFMA
 // pipe, is what limits the small tile (ds_write_b128 runs at ~79 B/clk/CU).
@@ -232,145 +379,7 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
 #undef GLDS_TILE
 #undef GLDS_ONE
 
-  // ---- epilogue A (256x256 tile, bf16 output): stage the wave's 128x64 sub-tile through LDS and finish it row-wise
-  // with 16-byte loads/stores (one full 128-byte line per 8 lanes): the 8-byte row-per-lane stores of epilogue B are
-  // store-ISSUE bound (17 us per tile = 18 % of a K=3072 GEMM); this form halves the store instructions and moves
-  // the gate / residual / aux traffic to 16-byte accesses too.
-  if (BIG && EPI != EPI_F32_ACC && g.rowwise_ok) {
-    char* reg = smem + wid * 16384;    // [128 rows][64 cols] bf16, 16-byte chunk index XOR (row & 7)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int row = j * 16 + fr;
-#pragma unroll
-      for (int i = 0; i < NTL; ++i) {
-        const long n = n0 + wn * 64 + i * 16 + fq * 4;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (g.bias && n < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-        }
-        uint2 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        const int c16 = i * 2 + (fq >> 1);
-        *reinterpret_cast<uint2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
-      }
-    }
-    // same-wave LDS ops complete in order; no block barrier needed (each wave owns its region)
-    const int rl = lane >> 3, c16 = lane & 7;
-    const long n = n0 + wn * 64 + c16 * 8;
-    long m = m0 + wm * 128 + rl;
-    long bidx = m / g.c.rpb;
-    long rin = m - bidx * g.c.rpb;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + rl;
-      if (m < g.M && n < g.N) {
-        const uint4 u = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
-        float v[8];
-        v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
-        v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
-        bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
-        if (EPI == EPI_BIAS_GELU) {
-          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
-        } else if (EPI == EPI_BIAS_GATE_RES) {
-          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
-          const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
-          const uint4 rr = *reinterpret_cast<const uint4*>(cp);
-          const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
-            v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
-          }
-        } else if (EPI == EPI_BIAS_MULAUX) {
-          const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
-          const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
-            v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
-          }
-        }
-        uint4 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        *reinterpret_cast<uint4*>(cp) = o;
-      }
-      m += 8;
-      rin += 8;
-      while (rin >= g.c.rpb) { rin -= g.c.rpb; ++bidx; }
-    }
-    return;
-  }
-
-  // ---- epilogue B: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const long m = m0 + wm * (MT * 16) + j * 16 + fr;
-    if (m >= g.M) continue;
-    const long crow = row_off(g.c, m);
-    const long bidx = m / g.c.rpb;
-#pragma unroll
-    for (int i = 0; i < NTL; ++i) {
-      const long n = n0 + wn * 64 + i * 16 + fq * 4;
-      if (n >= g.N) continue;   // N is a multiple of 4 (checked on the host)
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (EPI == EPI_F32_ACC) {
-        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + crow + n);
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (g.beta != 0.f) {
-          const float4 old = *cp;
-          o.x += g.beta * old.x; o.y += g.beta * old.y; o.z += g.beta * old.z; o.w += g.beta * old.w;
-        }
-        *cp = o;
-        continue;
-      }
-      if (g.bias) {
-        const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-        v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);   // the Linear's bf16 output
-      bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + n;
-      if (EPI == EPI_BIAS_GELU) {
-        if (g.aux) {  // keep the pre-activation for the backward pass
-          uint2 pre;
-          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
-      } else if (EPI == EPI_BIAS_GATE_RES) {
-        if (g.aux) {  // pre-gate branch output, needed for d(gate)
-          uint2 pre;
-          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
-        }
-        const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
-        const uint2 rr = *reinterpret_cast<const uint2*>(cp);
-        v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
-        v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
-        v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
-        v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
-      } else if (EPI == EPI_BIAS_MULAUX) {
-        // dgrad through GELU: C = (A@W^T) * gelu'(aux)   (aux = saved pre-activation)
-        const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + n);
-        v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
-        v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
-      }
-      uint2 o;
-      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      *reinterpret_cast<uint2*>(cp) = o;
-    }
-  }
+  gemm_epilogue<EPI, BIG, MT, NTL>(g, acc, smem, wid, lane, m0, n0, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------ transpose
