@@ -245,194 +245,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ 64 queries / wave
-// 4 waves x 64 queries (two 32-query blocks per wave), ONE wave per SIMD with the whole 512-register budget.  Every K
-// and Vt fragment read from LDS feeds two MFMAs (one per query block): half the LDS read traffic per MFMA of the
-// 32-query kernel, and the softmax VALU of one query block can be scheduled under the other block's MFMAs.
-__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(AttnArgs g) {
-  constexpr int NWAVE = 4, QBLK = 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | Vt tile]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int nq = (g.S + QBLK - 1) / QBLK;
-  const int nwg = nq * g.H * g.B;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  }
-  const int qt = bid % nq, bh = bid / nq;
-  const int b = bh / g.H, hh = bh - b * g.H;
-  const bf16_raw* Qp = g.Q + (long)bh * g.S * HD;
-  const bf16_raw* Kp = g.K + (long)bh * g.S * HD;
-  const bf16_raw* Vp = g.Vt + (long)bh * HD * g.Sp;
-
-  const int q0 = qt * QBLK + wid * 64;
-  s16x8 qf[2][8];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    int qrow = q0 + qb * 32 + r;
-    if (qrow >= g.S) qrow = g.S - 1;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      qf[qb][ks] = *reinterpret_cast<const s16x8*>(Qp + (long)qrow * HD + ks * 16 + h * 8);
-  }
-  const int kc_key0 = tid >> 4, kc_chunk = tid & 15;
-  const int vc_d0 = tid >> 3, vc_chunk = tid & 7;
-  constexpr int KSTEP = NWAVE * 4, DSTEP = NWAVE * 8;
-  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;
-  const int ntiles = (g.S + KB - 1) / KB;
-#define L1(i_, SK, SV)                                                                              \
-  {                                                                                                 \
-    int ka = key_base + kc_key0 + KSTEP * i_;                                                       \
-    if (ka >= g.S) ka = g.S - 1;                                                                    \
-    SK = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                        \
-    SV = *reinterpret_cast<const uint4*>(Vp + (long)(vc_d0 + DSTEP * i_) * g.Sp + key_base + vc_chunk * 8); \
-  }
-#define LOAD_KV64(t)                                                                                \
-  do {                                                                                              \
-    const int key_base = (t) * KB;                                                                  \
-    L1(0, sk0, sv0) L1(1, sk1, sv1) L1(2, sk2, sv2) L1(3, sk3, sv3)                                 \
-  } while (0)
-#define S1(i_, SK, SV)                                                                              \
-  {                                                                                                 \
-    *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0 + KSTEP * i_, kc_chunk)) = SK;                 \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk)) = make_uint2(SV.x, SV.y); \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk + 1)) = make_uint2(SV.z, SV.w); \
-  }
-#define STORE_KV64(buf)                                                                             \
-  do {                                                                                              \
-    char* kb_ptr = smem + (buf) * (K_TILE_BYTES + V_TILE_BYTES);                                    \
-    char* vb_ptr = kb_ptr + K_TILE_BYTES;                                                           \
-    S1(0, sk0, sv0) S1(1, sk1, sv1) S1(2, sk2, sv2) S1(3, sk3, sv3)                                 \
-  } while (0)
-
-  f32x16 o[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-
-  LOAD_KV64(0);
-  STORE_KV64(0);
-  __syncthreads();
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[0][ks]), "v"(qf[1][ks]));
-  int cur = 0;
-  auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
-    constexpr bool MASK = decltype(mask_tag)::value;
-    if (t + 1 < ntiles) LOAD_KV64(t + 1);
-    const char* ks_ = smem + cur * (K_TILE_BYTES + V_TILE_BYTES);
-    const char* vs_ = ks_ + K_TILE_BYTES;
-    f32x16 s[2][2];   // [query block][key block]
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const s16x8 kf = *reinterpret_cast<const s16x8*>(ks_ + k_off(kb * 32 + r, ks * 2 + h));
-        s[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][kb], 0, 0, 0);
-        s[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][kb], 0, 0, 0);
-      }
-    }
-    if (MASK) {
-      const int key_base = t * KB;
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (key >= g.S) s[qb][kb][i] = -INFINITY;
-          }
-    }
-    uint32_t pb[2][2][8];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float mx = s[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][kb][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * g.scale_log2e);
-      const float mc = m_new * g.scale_log2e;
-      m_run[qb] = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(s[qb][kb][i] * g.scale_log2e - mc);
-          const float p1 = __builtin_amdgcn_exp2f(s[qb][kb][i + 1] * g.scale_log2e - mc);
-          psum += p0 + p1;
-          pb[qb][kb][i >> 1] = pack_bf16(p0, p1);
-        }
-      l_run[qb] = l_run[qb] * alpha + psum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[qb][dt][i] *= alpha;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const s16x8 pf0 = __builtin_bit_cast(s16x8, make_uint4(pb[0][kb][4 * s2], pb[0][kb][4 * s2 + 1], pb[0][kb][4 * s2 + 2], pb[0][kb][4 * s2 + 3]));
-        const s16x8 pf1 = __builtin_bit_cast(s16x8, make_uint4(pb[1][kb][4 * s2], pb[1][kb][4 * s2 + 1], pb[1][kb][4 * s2 + 2], pb[1][kb][4 * s2 + 3]));
-        const int c8 = (kb * 32 + 16 * s2 + 4 * h) >> 2;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 32 + r;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8));
-          const uint2 hi = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8 + 2));
-          const s16x8 vf = __builtin_bit_cast(s16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-          o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0, o[0][dt], 0, 0, 0);
-          o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1, o[1][dt], 0, 0, 0);
-        }
-      }
-    if (t + 1 < ntiles) STORE_KV64(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  };
-  const int nfull = g.S / KB;
-  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-  if (nfull < ntiles) tile(nfull, std::true_type{});
-#undef L1
-#undef S1
-#undef LOAD_KV64
-#undef STORE_KV64
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + qb * 32 + r;
-    if (q < g.S) {
-      bf16_raw* op = g.O + (long)b * g.o_bstride + (long)q * g.ldo + hh * HD;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-          const int d = dt * 32 + 8 * i4 + 4 * h;
-          uint2 w;
-          w.x = pack_bf16(o[qb][dt][4 * i4] * inv, o[qb][dt][4 * i4 + 1] * inv);
-          w.y = pack_bf16(o[qb][dt][4 * i4 + 2] * inv, o[qb][dt][4 * i4 + 3] * inv);
-          *reinterpret_cast<uint2*>(op + d) = w;
-        }
-      if (g.lse && h == 0)
-        g.lse[(long)bh * g.S + q] = m_run[qb] * (g.scale_log2e * 0.6931471805599453f) + logf(l_tot);
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
@@ -445,10 +257,8 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   g.Q = Q; g.K = K; g.Vt = Vt; g.O = O; g.lse = lse;
   g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
   g.scale_log2e = scale * 1.4426950408889634f;
-  static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 4;
-  if (nw == 2) {
-    attn_fwd64_kernel<<<cdiv(S, 256) * H * B, 256, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
-  } else if (nw == 8) {
+  static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 8;
+  if (nw == 8) {
     attn_fwd_kernel<8><<<cdiv(S, 256) * H * B, 512, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
   } else {
     attn_fwd_kernel<4><<<cdiv(S, 128) * H * B, 256, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
