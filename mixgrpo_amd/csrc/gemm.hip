@@ -560,25 +560,41 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       else if (has_next) PGLDS_TILE(nap0, nap1, nap2, nap3, nwp0, nwp1, nwp2, nwp3, 0, cur ^ 1);
       const char* sa = smem + cur * STAGE;
       const char* sw = sa + TB;
+      // all 24 fragment reads of the K-tile in program order, then the 64 MFMAs; the scheduler is told to issue the
+      // reads TWO 8-MFMA groups ahead of their consumers (hipcc otherwise sinks every read next to its MFMA)
+      s16x8 fa[2][MT], fw[2][NTL];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        s16x8 fa[MT], fw[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
           const int rw_ = wn * 64 + t * 16 + fr;
-          fw[t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
+          fw[ks][t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const int ra_ = wm * 128 + t * 16 + fr;
-          fa[t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
+          fa[ks][t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
         }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
           for (int i = 0; i < NTL; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);     // groups 0,1,2 (6 + 2 + 2 reads)
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 3
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // group 4 (second k-step: 4 W + 2 A fragments)
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 5
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 6
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 7
+      __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
