@@ -1,0 +1,69 @@
+"""Two-rank data-parallel train step on ONE GPU (gloo backend, both ranks on cuda:0): the collective sequence of the
+engine (reward all-gather, flat-gradient all-reduce, logging vector, barrier) runs to completion, both replicas end
+with bit-identical weights, and the update equals a single-process step on the averaged gradient."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=4, joint_attention_dim=64,
+           pooled_projection_dim=32)
+
+
+def _one_step(rank, world, seed_prompt):
+    from mixgrpo_amd import train_grpo_flux as TG
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    from mixgrpo_amd.optim import ConstantWithWarmup, FusedAdamW
+    dev = torch.device("cuda", 0)
+    m = FluxTransformer2DModel(FluxConfig(**CFG), device=dev).init_synthetic(seed=5, std=0.05, bias_std=0.02)
+    opt = FusedAdamW(m, lr=1e-3)
+    args = TG.default_args(h=48, w=64, sampling_steps=6, num_generations=4, gradient_accumulation_steps=2)
+    g = torch.Generator().manual_seed(seed_prompt)
+    batch = ((0.1 * torch.randn(1, 16, 64, generator=g)).bfloat16().to(dev), torch.randn(1, 32, generator=g).bfloat16().to(dev),
+             torch.zeros(1, 3, device=dev), ["p"])
+    inj = {"x_T": torch.randn(1, 16, 6, 8, generator=g).bfloat16(),
+           "steps": [torch.randn(4, 12, 64, generator=g).bfloat16() for _ in range(6)]}
+    args.injected_noise = inj
+
+    def reward(lat, cap):
+        r = torch.tensor([0.1, 0.4, 0.2, 0.9]) + 0.05 * seed_prompt
+        return r, {"Synthetic": r}
+
+    res = TG.train_one_step(args, dev, m, None, reward, opt, ConstantWithWarmup(opt, 0), iter([batch]), None, 1.0, [1, 2], 0,
+                            {"Synthetic": 1.0})
+    torch.cuda.synchronize()
+    return res, m
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res, m = _one_step(rank, world, seed_prompt=rank + 1)
+    w = m.store.w32.detach().cpu()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, res, w.double().sum().item(), w[:4096].tolist(), w.abs().max().item()))   # plain python objects only
+
+
+def test_two_rank_step_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, res0, s0, head0, mx0), (r1, res1, s1, head1, mx1) = out
+    assert s0 == s1 and head0 == head1 and mx0 == mx1          # replicas stay in lockstep
+    assert res0[0] == pytest.approx(res1[0])                              # logged loss is the rank average
+    assert res0[1] == pytest.approx(res1[1]) and res0[1] > 0             # global grad norm of the averaged gradient
+    assert res0[5]["Synthetic"] == pytest.approx(res1[5]["Synthetic"])  # gathered reward mean over both ranks
+    assert all(x == x for x in (res0[0], res0[1], res0[2]))
