@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--train-microbatch", type=int, default=6)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", default=None, help="write the per-shape GEMM time table of the roofline step here")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,9 +147,22 @@ def main():
         ops.GEMM_PROFILE = []
         one_step()
         torch.cuda.synchronize()
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ops.GEMM_PROFILE)
-        tot_fl = sum(f for _, _, f in ops.GEMM_PROFILE)
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ops.GEMM_PROFILE)
+        tot_fl = sum(f for _, _, f, _ in ops.GEMM_PROFILE)
         n_launch = len(ops.GEMM_PROFILE)
+        if a.gemm_shapes:
+            agg = {}
+            for e0, e1, f, shp in ops.GEMM_PROFILE:
+                c = agg.setdefault(shp, [0, 0.0, 0.0])
+                c[0] += 1
+                c[1] += e0.elapsed_time(e1)
+                c[2] += f
+            rows = [{"M": k[0], "N": k[1], "K": k[2], "epilogue": k[3], "calls": v[0], "total_ms": round(v[1], 2),
+                     "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in agg.items()]
+            rows.sort(key=lambda r: -r["total_ms"])
+            with open(a.gemm_shapes, "w") as fh:
+                for r in rows:
+                    fh.write(json.dumps(r) + "\n")
         ops.GEMM_PROFILE = None
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<EPI> (bf16 MFMA 128x128x64, all epilogues)",

@@ -23,13 +23,14 @@ constexpr int NT = 256;
 
 struct RowMap {
   long ld;       // elements between consecutive rows inside a batch
-  long rpb;      // rows per batch (>= M for a plain matrix)
+  long rpb;      // rows per batch (>= M for a plain matrix; the host clamps it to 2^30 so 32-bit division applies)
   long bstride;  // elements between batches
 };
 
 __device__ __forceinline__ long row_off(const RowMap& r, long m) {
-  const long b = m / r.rpb;
-  return b * r.bstride + (m - b * r.rpb) * r.ld;
+  const uint32_t rpb = (uint32_t)r.rpb;
+  const uint32_t b = (uint32_t)m / rpb;         // M < 2^31 and rpb <= 2^30: a 32-bit division (a 64-bit one is ~120 instructions)
+  return (long)b * r.bstride + (long)((uint32_t)m - b * rpb) * r.ld;
 }
 
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2, EPI_F32_ACC = 3, EPI_BIAS_MULAUX = 4 };
@@ -48,20 +49,24 @@ struct GemmArgs {
   long ldw;
   float beta;             // EPI_F32_ACC: C = beta*C + acc
   int rowwise_ok;         // all bf16 side operands are 16-byte addressable: the LDS-staged epilogue may be used
+  int span32;             // both operands span < 4 GiB: the persistent kernel's 32-bit DMA source offsets are valid
 };
 
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
+// gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With tanh(u) = 2 s - 1, s = 1 / (1 + e^{-2u}):
+// gelu = x s and gelu' = s + 2 x s (1 - s) u'.  One v_exp_f32 + one v_rcp_f32 per element instead of the ~40-instruction
+// ocml tanhf (the epilogue of a 256x256 tile evaluates it 65,536 times; both agree to < 1 ulp of the bf16 result).
+__device__ __forceinline__ float gelu_sigmoid_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  const float c = -2.0f * k0 * 1.4426950408889634f;            // e^{-2u} = 2^{c x (1 + k1 x^2)}
+  const float e = __builtin_amdgcn_exp2f(c * x * __builtin_fmaf(k1 * x, x, 1.0f));
+  return __builtin_amdgcn_rcpf(1.0f + e);
 }
+__device__ __forceinline__ float gelu_tanh_f(float x) { return x * gelu_sigmoid_f(x); }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  const float t = tanhf(u);
-  const float du = k0 * (1.0f + 3.0f * k1 * x * x);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  const float s = gelu_sigmoid_f(x);
+  const float du = k0 * __builtin_fmaf(3.0f * k1 * x, x, 1.0f);
+  return __builtin_fmaf(2.0f * x * s * (1.0f - s), du, s);
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -100,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NT
     const int rl = lane >> 3, c16 = lane & 7;
     const long n = n0 + wn * 64 + c16 * 8;
     long m = m0 + wm * 128 + rl;
-    long bidx = m / g.c.rpb;
+    long bidx = (uint32_t)m / (uint32_t)g.c.rpb;
     long rin = m - bidx * g.c.rpb;
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
@@ -154,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NT
     const long m = m0 + wm * (MT * 16) + j * 16 + fr;
     if (m >= g.M) continue;
     const long crow = row_off(g.c, m);
-    const long bidx = m / g.c.rpb;
+    const long bidx = (uint32_t)m / (uint32_t)g.c.rpb;
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
       const long n = n0 + wn * 64 + i * 16 + fq * 4;
@@ -473,9 +478,287 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
 
 // ------------------------------------------------------------------------------------------ persistent variant
 // One workgroup per CU walks a strided list of 256x256 tiles.  The first K-tile of the NEXT tile is DMA'd into the
-// idle LDS buffer during the last K-step of the current one (no exposed prologue, no dispatch gap between tiles), the
-// epilogue stages through the buffer that was just consumed (two 64-row passes per wave: 64 KiB), and its global
-// stores drain underneath the next tile's K-loop.
+// idle LDS buffer during the last K-step of the current one (no exposed prologue, no dispatch gap between tiles) and
+// the epilogue's global stores drain underneath the next tile's K-loop.
+//
+// Output layout trick: the W rows of each 64-row wave group are stored in LDS in the order
+//     LDS row t*16 + f  <-  W row (f>>2)*16 + t*4 + (f&3)            (the DMA source address is per lane: free)
+// so the accumulators acc[t = 0..3][j] of lane (fr, fq) are 16 CONSECUTIVE output features fq*16 + t*4 + r of token
+// row j*16 + fr: the epilogue runs straight from registers with 16-byte accesses (4 lanes = one 128-byte line per
+// row), with no LDS transpose, no bf16 round trip and no barrier before the next tile.
+//
+// Everything the epilogue reads from memory is requested UNCONDITIONALLY (clamped addresses) and in batches: a
+// per-row `if (in range) { load; use; store }` makes hipcc emit branch + load + s_waitcnt vmcnt(0) per row, i.e.
+// serial HBM round trips (vmcnt counts stores too, so each wait also drains the previous row's store): that form
+// cost ~20 us of an 80 us K=3072 tile.
+__device__ __forceinline__ int wperm(int p) { return ((p & 15) >> 2) * 16 + (p >> 4) * 4 + (p & 3); }
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* v) {
+  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+  v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint4 o;
+  o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  return o;
+}
+
+template <int EPI>
+__device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int wid, int lane, long m0,
+                                                 long n0) {
+  constexpr int MT = 8;
+  const int wm = wid >> 2, wn = wid & 3, fr = lane & 15, fq = lane >> 4;
+  const long n = n0 + wn * 64 + fq * 16;          // this lane's 16 consecutive output features
+  // N % 4 == 0 always; on the 16-byte paths N % 8 == 0: the two 8-feature halves are in range independently
+  const long mrow0 = m0 + wm * 128 + fr;          // rows mrow0 + 16 j
+
+  if (EPI == EPI_F32_ACC) {
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const bool rmw = g.beta != 0.f;
+    bool nok[4];
+    long ncol[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      nok[t] = n + t * 4 < g.N;
+      ncol[t] = nok[t] ? n + t * 4 : 0;
+    }
+#pragma unroll
+    for (int jb = 0; jb < MT; jb += 2) {          // two rows (8 float4) of read-modify-write loads in flight
+      long off[2];
+      bool rok[2];
+      float4 old[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const long m = mrow0 + (jb + jj) * 16;
+        rok[jj] = m < g.M;
+        off[jj] = rok[jj] ? row_off(g.c, m) : 0;
+      }
+      if (rmw) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) old[jj][t] = *reinterpret_cast<const float4*>(Cb + off[jj] + ncol[t]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 a = acc[t][jb + jj];
+          float4 o = make_float4(a[0], a[1], a[2], a[3]);
+          if (rmw) {
+            o.x += g.beta * old[jj][t].x; o.y += g.beta * old[jj][t].y;
+            o.z += g.beta * old[jj][t].z; o.w += g.beta * old[jj][t].w;
+          }
+          if (rok[jj] && nok[t]) *reinterpret_cast<float4*>(Cb + off[jj] + ncol[t]) = o;
+        }
+    }
+    return;
+  }
+
+  if (!g.rowwise_ok) {
+    // generic (side operands only 8-byte addressable): 4 features per access
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const long m = mrow0 + j * 16;
+      if (m >= g.M) continue;
+      const long crow = row_off(g.c, m);
+      const long bidx = (uint32_t)m / (uint32_t)g.c.rpb;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long nn = n + t * 4;
+        if (nn >= g.N) continue;
+        float v[4] = {acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]};
+        if (g.bias) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + nn);
+          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + nn;
+        uint2 pre;
+        pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        if (EPI == EPI_BIAS_GELU) {
+          if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + nn) = pre;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+        } else if (EPI == EPI_BIAS_GATE_RES) {
+          if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + nn) = pre;
+          const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + nn);
+          const uint2 rr = *reinterpret_cast<const uint2*>(cp);
+          v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
+          v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
+          v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
+          v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
+        } else if (EPI == EPI_BIAS_MULAUX) {
+          const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + nn);
+          v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
+          v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
+        }
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(cp) = o;
+      }
+    }
+    return;
+  }
+
+  // ---- 16-byte path.  Order: (1) request bias, gate and the side operands of rows 0..3; (2) retire all 128
+  // accumulator registers into 64 registers of packed bf16 Linear outputs y = bf16(acc + bias); (3) finish the rows in
+  // 2-row batches, each batch re-requesting the side operands four rows ahead BEFORE its own stores (vmcnt is in order
+  // and counts stores: a load issued after a store cannot be waited for without draining the store).
+  // Addressing: wave-uniform base (scalar registers) + one 32-bit per-lane byte offset per row; rows / columns outside
+  // the matrix are clamped to the last valid row / the wave's first column for the loads and masked for the stores.
+  // The wave's 128 rows lie in ONE batch (c_rpb % 128 == 0 or a plain matrix: part of rowwise_ok).
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const long mu = m0 + (wu >> 2) * 128, nu = n0 + (wu & 3) * 64;
+  if (mu >= g.M || nu >= g.N) return;               // wave-uniform: nothing of this wave's block is inside the matrix
+  const long bu = (uint32_t)mu / (uint32_t)g.c.rpb;
+  const char* cbase = reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + nu) * 2;
+  const char* abase = reinterpret_cast<const char*>(g.aux) + (mu * g.ldaux + nu) * 2;
+  const int rmax = (int)(g.M - 1 - mu < 127 ? g.M - 1 - mu : 127);      // last valid row of the block
+  const bool nok0 = nu + fq * 16 < g.N, nok1 = nu + fq * 16 + 8 < g.N;   // N % 8 == 0 on this path
+  const uint32_t c0 = nok0 ? fq * 32 : 0, c1 = nok1 ? fq * 32 + 16 : 0;  // byte offsets of the two 8-feature halves
+  const uint32_t ldc2 = (uint32_t)(g.c.ld * 2), lda2 = (uint32_t)(g.ldaux * 2);
+  auto rowclamp = [&](int j) { const int r = fr + 16 * j; return (uint32_t)(r < rmax ? r : rmax); };
+
+  uint4 bias0 = make_uint4(0, 0, 0, 0), bias1 = bias0;
+  if (g.bias) {
+    const char* bb = reinterpret_cast<const char*>(g.bias) + nu * 2;
+    bias0 = *reinterpret_cast<const uint4*>(bb + c0);
+    bias1 = *reinterpret_cast<const uint4*>(bb + c1);
+  }
+  constexpr bool SIDE = EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_MULAUX;
+  uint4 gate0 = make_uint4(0, 0, 0, 0), gate1 = gate0;
+  if (EPI == EPI_BIAS_GATE_RES) {
+    const char* gp = reinterpret_cast<const char*>(g.gate) + (bu * g.gate_ld + nu) * 2;
+    gate0 = *reinterpret_cast<const uint4*>(gp + c0);
+    gate1 = *reinterpret_cast<const uint4*>(gp + c1);
+  }
+  uint4 side[2][SIDE ? 2 : 1][2];                   // [ring slot][row of the 2-row batch][feature half]
+  // `dep` is an opaque zero that is data-dependent on the previous batch's results: without it hipcc hoists ALL side
+  // loads to the top of the epilogue, runs out of registers and spills the loaded data (scratch + vmcnt(0) per load)
+  auto load_side = [&](int h, int j0, uint32_t dep) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t ro = (rowclamp(j0 + k) + dep) * (EPI == EPI_BIAS_GATE_RES ? ldc2 : lda2);
+      const char* base = EPI == EPI_BIAS_GATE_RES ? cbase : abase;
+      side[h][SIDE ? k : 0][0] = *reinterpret_cast<const uint4*>(base + (ro + c0));
+      side[h][SIDE ? k : 0][1] = *reinterpret_cast<const uint4*>(base + (ro + c1));
+    }
+  };
+  if (SIDE) {
+    load_side(0, 0, 0);
+    load_side(1, 2, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 y[MT][2];
+  {
+    float bias[16];
+    unpack8(bias0, bias);
+    unpack8(bias1, bias + 8);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
+      y[j][0] = pack8(v);
+      y[j][1] = pack8(v + 8);
+      __builtin_amdgcn_sched_barrier(0);           // row by row: interleaving the rows doubles the live registers
+    }
+  }
+#pragma unroll
+  for (int jb = 0; jb < MT; jb += 2) {
+    const int slot = (jb >> 1) & 1;
+    uint4 o[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jb + jj;
+      if (EPI == EPI_BIAS) {
+        o[jj][0] = y[j][0];
+        o[jj][1] = y[j][1];
+      } else {
+        float v[16];
+        unpack8(y[j][0], v);
+        unpack8(y[j][1], v + 8);
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = gelu_tanh_f(v[e]);
+        } else if (EPI == EPI_BIAS_GATE_RES) {
+          float gv[16], rv[16];
+          unpack8(gate0, gv);
+          unpack8(gate1, gv + 8);
+          unpack8(side[slot][SIDE ? jj : 0][0], rv);
+          unpack8(side[slot][SIDE ? jj : 0][1], rv + 8);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = rv[e] + rbf(gv[e] * v[e]);
+        } else if (EPI == EPI_BIAS_MULAUX) {
+          float pv[16];
+          unpack8(side[slot][SIDE ? jj : 0][0], pv);
+          unpack8(side[slot][SIDE ? jj : 0][1], pv + 8);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] *= gelu_tanh_grad_f(pv[e]);
+        }
+        o[jj][0] = pack8(v);
+        o[jj][1] = pack8(v + 8);
+      }
+    }
+    if (SIDE && jb + 4 < MT) {                      // rows jb + 4, jb + 5 into the slot just consumed
+      uint32_t dep = 0;
+      asm volatile("" : "+v"(dep) : "v"(o[1][1].w));
+      load_side(slot, jb + 4, dep);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jb + jj;
+      const int r = fr + 16 * j;
+      if (r <= rmax) {
+        char* cb = const_cast<char*>(cbase);
+        const uint32_t co = (uint32_t)r * ldc2;
+        if ((EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GATE_RES) && g.aux) {
+          char* ab = const_cast<char*>(abase);      // pre-activation / pre-gate branch output for the backward pass
+          const uint32_t ao = (uint32_t)r * lda2;
+          if (nok0) *reinterpret_cast<uint4*>(ab + (ao + c0)) = y[j][0];
+          if (nok1) *reinterpret_cast<uint4*>(ab + (ao + c1)) = y[j][1];
+        }
+        if (nok0) *reinterpret_cast<uint4*>(cb + (co + c0)) = o[jj][0];
+        if (nok1) *reinterpret_cast<uint4*>(cb + (co + c1)) = o[jj][1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// L2 prefetch of the tile's side operand (residual rows of C, or the saved pre-activation): one 4-byte LDS-DMA per
+// 128-byte line into a junk LDS area (a DMA needs no destination register).  Issued with the last K-tile's DMA, it is
+// retired by that iteration's vmcnt(0) together with the next tile's first K-tile.
+template <int EPI>
+__device__ __forceinline__ void prefetch_side(const GemmArgs& g, char* junk, int wid, int lane, long m0, long n0) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef const __attribute__((address_space(1))) char gbl_char;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const long mu = m0 + (wu >> 2) * 128, nu = n0 + (wu & 3) * 64;
+  if (mu >= g.M || nu >= g.N) return;
+  const long bu = (uint32_t)mu / (uint32_t)g.c.rpb;
+  const char* base = EPI == EPI_BIAS_GATE_RES
+                         ? reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + nu) * 2
+                         : reinterpret_cast<const char*>(g.aux) + (mu * g.ldaux + nu) * 2;
+  const uint32_t ld2 = (uint32_t)((EPI == EPI_BIAS_GATE_RES ? g.c.ld : g.ldaux) * 2);
+  const int rmax = (int)(g.M - 1 - mu < 127 ? g.M - 1 - mu : 127);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = q * 64 + lane;
+    const uint32_t off = (uint32_t)(r < rmax ? r : rmax) * ld2;
+    __builtin_amdgcn_global_load_lds((gbl_char*)(base + off), (lds_char*)(junk + wu * 512 + q * 256), 4, 0, 0);
+  }
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, STAGE = 2 * TB, MT = 8, NTL = 4;
@@ -497,9 +780,12 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 
   const int lrow = tid >> 3, lkc = tid & 7;
   const int src_kc = swz(lrow, lkc);
+  const int wrow = wperm(lrow);                    // W row (inside its 64-row group) that lands in LDS row lrow
   typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) bf16_raw gbl_bf16;
-  const bf16_raw *ap0, *ap1, *ap2, *ap3, *wp0, *wp1, *wp2, *wp3;
+  typedef const __attribute__((address_space(1))) char gbl_char;
+  // per-lane DMA sources as 32-bit BYTE offsets from the (uniform) operand bases: the host checks both operands
+  // span < 4 GiB.  Half the registers of 64-bit pointers, and the uniform K offset folds into the scalar base.
+  uint32_t ao[4], wo[4];
   long m0, n0;
 #define TILE_COORDS(tl, M0, N0)                                            \
   do {                                                                     \
@@ -510,33 +796,33 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     M0 = (long)(b0 * band + in_band % rows_in_band) * TM;                  \
     N0 = (long)(in_band / rows_in_band) * TN;                              \
   } while (0)
-#define TILE_PTRS(M0, N0, A0, A1, A2, A3, W0, W1, W2, W3)                                  \
+#define TILE_OFFS(M0, N0, AO, WO)                                                          \
   do {                                                                                     \
-    long mm, nn;                                                                           \
-    mm = M0 + lrow;          if (mm >= g.M) mm = g.M - 1; A0 = g.A + row_off(g.a, mm) + src_kc * 8; \
-    mm = M0 + lrow + RS;     if (mm >= g.M) mm = g.M - 1; A1 = g.A + row_off(g.a, mm) + src_kc * 8; \
-    mm = M0 + lrow + 2 * RS; if (mm >= g.M) mm = g.M - 1; A2 = g.A + row_off(g.a, mm) + src_kc * 8; \
-    mm = M0 + lrow + 3 * RS; if (mm >= g.M) mm = g.M - 1; A3 = g.A + row_off(g.a, mm) + src_kc * 8; \
-    nn = N0 + lrow;          if (nn >= g.N) nn = g.N - 1; W0 = g.W + nn * g.ldw + src_kc * 8; \
-    nn = N0 + lrow + RS;     if (nn >= g.N) nn = g.N - 1; W1 = g.W + nn * g.ldw + src_kc * 8; \
-    nn = N0 + lrow + 2 * RS; if (nn >= g.N) nn = g.N - 1; W2 = g.W + nn * g.ldw + src_kc * 8; \
-    nn = N0 + lrow + 3 * RS; if (nn >= g.N) nn = g.N - 1; W3 = g.W + nn * g.ldw + src_kc * 8; \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
+      long mm = M0 + lrow + k_ * RS;                                                       \
+      if (mm >= g.M) mm = g.M - 1;                                                         \
+      AO[k_] = (uint32_t)((row_off(g.a, mm) + src_kc * 8) * 2);                            \
+      long nn = N0 + k_ * 64 + wrow;                                                       \
+      if (nn >= g.N) nn = g.N - 1;                                                         \
+      WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
+    }                                                                                      \
   } while (0)
-#define PGLDS_ONE(gp, ko, off) \
-  __builtin_amdgcn_global_load_lds((gbl_bf16*)((gp) + (ko)), (lds_char*)(smem + (off)), 16, 0, 0)
-#define PGLDS_TILE(A0, A1, A2, A3, W0, W1, W2, W3, kt, buf)                                                   \
+#define PGLDS_ONE(base, off, off_lds) \
+  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
+#define PGLDS_TILE(AO, WO, kt, buf)                                                                           \
   do {                                                                                                        \
-    const long ko = (long)(kt) * BK;                                                                          \
-    const int wb_ = (buf) * STAGE + wid * 1024;                                                               \
-    PGLDS_ONE(A0, ko, wb_); PGLDS_ONE(A1, ko, wb_ + RS * 128); PGLDS_ONE(A2, ko, wb_ + 2 * RS * 128);         \
-    PGLDS_ONE(A3, ko, wb_ + 3 * RS * 128);                                                                    \
-    PGLDS_ONE(W0, ko, wb_ + TB); PGLDS_ONE(W1, ko, wb_ + TB + RS * 128); PGLDS_ONE(W2, ko, wb_ + TB + 2 * RS * 128); \
-    PGLDS_ONE(W3, ko, wb_ + TB + 3 * RS * 128);                                                               \
+    const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)(kt) * (BK * 2);                             \
+    const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)(kt) * (BK * 2);                             \
+    const int lb_ = (buf) * STAGE + wid * 1024;                                                               \
+    PGLDS_ONE(ab_, AO[0], lb_); PGLDS_ONE(ab_, AO[1], lb_ + RS * 128); PGLDS_ONE(ab_, AO[2], lb_ + 2 * RS * 128); \
+    PGLDS_ONE(ab_, AO[3], lb_ + 3 * RS * 128);                                                                \
+    PGLDS_ONE(wb_, WO[0], lb_ + TB); PGLDS_ONE(wb_, WO[1], lb_ + TB + RS * 128);                              \
+    PGLDS_ONE(wb_, WO[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, WO[3], lb_ + TB + 3 * RS * 128);           \
   } while (0)
 
   TILE_COORDS(t_lin, m0, n0);
-  TILE_PTRS(m0, n0, ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3);
-  PGLDS_TILE(ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3, 0, 0);
+  TILE_OFFS(m0, n0, ao, wo);
+  PGLDS_TILE(ao, wo, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -544,10 +830,10 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     const int t_next = t_lin + per_xcd_wg;
     const bool has_next = t_next < xend;
     long nm0 = 0, nn0 = 0;
-    const bf16_raw *nap0 = ap0, *nap1 = ap1, *nap2 = ap2, *nap3 = ap3, *nwp0 = wp0, *nwp1 = wp1, *nwp2 = wp2, *nwp3 = wp3;
+    uint32_t nao[4] = {ao[0], ao[1], ao[2], ao[3]}, nwo[4] = {wo[0], wo[1], wo[2], wo[3]};
     if (has_next) {
       TILE_COORDS(t_next, nm0, nn0);
-      TILE_PTRS(nm0, nn0, nap0, nap1, nap2, nap3, nwp0, nwp1, nwp2, nwp3);
+      TILE_OFFS(nm0, nn0, nao, nwo);
     }
     f32x4 acc[NTL][MT];
 #pragma unroll
@@ -556,8 +842,16 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) PGLDS_TILE(ap0, ap1, ap2, ap3, wp0, wp1, wp2, wp3, kt + 1, cur ^ 1);
-      else if (has_next) PGLDS_TILE(nap0, nap1, nap2, nap3, nwp0, nwp1, nwp2, nwp3, 0, cur ^ 1);
+      if (kt + 1 < nkt) {
+        PGLDS_TILE(ao, wo, kt + 1, cur ^ 1);
+      } else {
+        if (has_next) PGLDS_TILE(nao, nwo, 0, cur ^ 1);
+        if ((EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_MULAUX) && g.rowwise_ok) {
+          int pl = lane, pw = wid;      // opaque copies: keeps the address arithmetic from being hoisted out of the K-loop
+          asm volatile("" : "+v"(pl), "+v"(pw));
+          prefetch_side<EPI>(g, smem + 2 * STAGE, pw, pl, m0, n0);
+        }
+      }
       const char* sa = smem + cur * STAGE;
       const char* sw = sa + TB;
       // all 24 fragment reads of the K-tile in program order, then the 64 MFMAs; the scheduler is told to issue the
@@ -599,153 +893,20 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       __syncthreads();
       cur ^= 1;
     }
-    // ---------------- epilogue of tile (m0, n0); staging buffer = the stage just consumed (cur ^ 1)
-    if (EPI == EPI_F32_ACC || !g.rowwise_ok) {
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const long m = m0 + wm * 128 + j * 16 + fr;
-        if (m >= g.M) continue;
-        const long crow = row_off(g.c, m);
-        const long bidx = m / g.c.rpb;
-#pragma unroll
-        for (int i = 0; i < NTL; ++i) {
-          const long n = n0 + wn * 64 + i * 16 + fq * 4;
-          if (n >= g.N) continue;
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (EPI == EPI_F32_ACC) {
-            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + crow + n);
-            float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            if (g.beta != 0.f) {
-              const float4 old = *cp;
-              o.x += g.beta * old.x; o.y += g.beta * old.y; o.z += g.beta * old.z; o.w += g.beta * old.w;
-            }
-            *cp = o;
-            continue;
-          }
-          if (g.bias) {
-            const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-            v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-          bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + crow + n;
-          uint2 pre;
-          pre.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pre.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          if (EPI == EPI_BIAS_GELU) {
-            if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
-          } else if (EPI == EPI_BIAS_GATE_RES) {
-            if (g.aux) *reinterpret_cast<uint2*>(g.aux + m * g.ldaux + n) = pre;
-            const uint2 gg = *reinterpret_cast<const uint2*>(g.gate + bidx * g.gate_ld + n);
-            const uint2 rr = *reinterpret_cast<const uint2*>(cp);
-            v[0] = bf2f(rr.x & 0xffff) + rbf(bf2f(gg.x & 0xffff) * v[0]);
-            v[1] = bf2f(rr.x >> 16) + rbf(bf2f(gg.x >> 16) * v[1]);
-            v[2] = bf2f(rr.y & 0xffff) + rbf(bf2f(gg.y & 0xffff) * v[2]);
-            v[3] = bf2f(rr.y >> 16) + rbf(bf2f(gg.y >> 16) * v[3]);
-          } else if (EPI == EPI_BIAS_MULAUX) {
-            const uint2 pp = *reinterpret_cast<const uint2*>(g.aux + m * g.ldaux + n);
-            v[0] *= gelu_tanh_grad_f(bf2f(pp.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(pp.x >> 16));
-            v[2] *= gelu_tanh_grad_f(bf2f(pp.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(pp.y >> 16));
-          }
-          uint2 o;
-          o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(cp) = o;
-        }
-      }
-    } else {
-      char* reg = smem + (cur ^ 1) * STAGE + wid * 8192;    // [64 rows][64 cols] bf16 per pass, chunk XOR (row & 7)
-      const int rl = lane >> 3, c16 = lane & 7;
-      const long n = n0 + wn * 64 + c16 * 8;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = half * 4 + jj;
-          const int row = jj * 16 + fr;
-#pragma unroll
-          for (int i = 0; i < NTL; ++i) {
-            const long nb = n0 + wn * 64 + i * 16 + fq * 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (g.bias && nb < g.N) {
-              const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + nb);
-              v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-            }
-            uint2 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            const int cc = i * 2 + (fq >> 1);
-            *reinterpret_cast<uint2*>(reg + row * 128 + ((cc ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
-          }
-        }
-        long m = m0 + wm * 128 + half * 64 + rl;
-        long bidx = m / g.c.rpb;
-        long rin = m - bidx * g.c.rpb;
-        // all 8 row reads of the pass are requested before any is consumed
-        uint4 u[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int row = it * 8 + rl;
-          u[it] = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          if (m < g.M && n < g.N) {
-            bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
-            if (EPI == EPI_BIAS) {
-              *reinterpret_cast<uint4*>(cp) = u[it];
-            } else {
-              float v[8];
-              v[0] = bf2f(u[it].x & 0xffff); v[1] = bf2f(u[it].x >> 16); v[2] = bf2f(u[it].y & 0xffff); v[3] = bf2f(u[it].y >> 16);
-              v[4] = bf2f(u[it].z & 0xffff); v[5] = bf2f(u[it].z >> 16); v[6] = bf2f(u[it].w & 0xffff); v[7] = bf2f(u[it].w >> 16);
-              if (EPI == EPI_BIAS_GELU) {
-                if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u[it];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
-              } else if (EPI == EPI_BIAS_GATE_RES) {
-                if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u[it];
-                const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
-                const uint4 rr = *reinterpret_cast<const uint4*>(cp);
-                const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
-                  v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
-                }
-              } else if (EPI == EPI_BIAS_MULAUX) {
-                const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
-                const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
-                  v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
-                }
-              }
-              uint4 o;
-              o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-              o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-              o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-              o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-              *reinterpret_cast<uint4*>(cp) = o;
-            }
-          }
-          m += 8;
-          rin += 8;
-          if (rin >= g.c.rpb) { bidx = m / g.c.rpb; rin = m - bidx * g.c.rpb; }
-        }
-      }
-    }
+    // the epilogue touches no LDS: the next tile's K-loop (whose first K-tile is already resident) follows directly.
+    // Its lane-dependent addressing starts from opaque copies so that none of it is computed before the K-loop and
+    // kept alive across it (the loop runs at the 256-VGPR limit; a reload inside it also drains the DMA queue).
+    int el = lane, ew = wid;
+    asm volatile("" : "+v"(el), "+v"(ew));
+    persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
     if (!has_next) break;
-    // the next tile's first DMA (issued at kt = 0 of its K-loop) targets the staging buffer: all waves must be done
-    __syncthreads();
     t_lin = t_next;
     m0 = nm0; n0 = nn0;
-    ap0 = nap0; ap1 = nap1; ap2 = nap2; ap3 = nap3; wp0 = nwp0; wp1 = nwp1; wp2 = nwp2; wp3 = nwp3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
   }
 #undef TILE_COORDS
-#undef TILE_PTRS
+#undef TILE_OFFS
 #undef PGLDS_ONE
 #undef PGLDS_TILE
 }
@@ -761,14 +922,14 @@ int launch(const GemmArgs& g, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
     attr_set = true;
   }
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 4;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA, 4: persistent
-  if (big && mode == 4) {
+  if (big && mode == 4 && g.span32) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    gemm_persist_kernel<EPI><<<grid, 512, 131072, st>>>(g);
+    gemm_persist_kernel<EPI><<<grid, 512, 131072 + 4096, st>>>(g);   // + junk area of prefetch_side
   } else if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   else if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
   else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);
@@ -794,13 +955,18 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   GemmArgs g;
   g.A = A; g.W = W; g.bias = bias; g.C = C; g.gate = gate; g.aux = aux; g.ldaux = ldaux; g.gate_ld = gate_ld;
   g.M = M; g.N = N; g.K = K;
-  g.a = RowMap{lda, a_rpb, a_bstride};
-  g.c = RowMap{ldc, c_rpb, c_bstride};
+  const long RPB_MAX = 1L << 30;
+  g.a = RowMap{lda, a_rpb < RPB_MAX ? a_rpb : RPB_MAX, a_bstride};
+  g.c = RowMap{ldc, c_rpb < RPB_MAX ? c_rpb : RPB_MAX, c_bstride};
   g.ldw = ldw;
   g.beta = beta;
-  g.rowwise_ok = (N % 8 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
+  g.rowwise_ok = (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
                  (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
-                 (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 8 == 0);
+                 (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
+  {
+    const long a_last = (long)((M - 1) / a_rpb) * a_bstride + (long)((M - 1) % a_rpb) * lda + K;
+    g.span32 = a_last * 2 < (1L << 32) && ((long)N * ldw) * 2 < (1L << 32);
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case EPI_BIAS: return launch<EPI_BIAS>(g, st);
@@ -830,11 +996,11 @@ extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* cols
                     ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
   if (fast) {
     dim3 grid(cdiv(N, 128), cdiv(ld_out, 128));
-    transpose8_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
+    transpose8_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
     if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 128), N, colsum_beta);
   } else {
     dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
-    transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb, in_bstride}, ld_out);
+    transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
     if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
   }
   MGX_CHECK_LAUNCH();

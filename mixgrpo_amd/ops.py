@@ -36,7 +36,7 @@ def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, au
         e0.record()
         _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux)
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * A.M * N * K))
+        GEMM_PROFILE.append((e0, e1, 2.0 * A.M * N * K, (A.M, N, K, epi)))
         return
     _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux)
 

@@ -1,0 +1,140 @@
+"""GPU parity of `mgx_gemm_bf16` (csrc/gemm.hip) against a plain fp32 torch reference of the same op, through the
+C ABI.  The shapes are chosen so that BOTH kernel families run: the persistent 256x256 kernel (>= 192 tiles) and the
+128x128 kernel (small problems), with ragged M / N edges, row-batched A and C operands whose batch boundaries fall
+inside tiles, and every fused epilogue.
+
+Tolerance: bf16 operands, fp32 MFMA accumulation in a different summation order than the reference; the Linear's bf16
+output y may differ from the rounded reference by one bf16 ulp on values that sit on a rounding boundary, and the fused
+epilogue propagates such a flip with slope `amp` (GELU <= 1.13, gate: |gate|, GELU': <= 1.13):
+|diff| <= 2^-7 * |ref| + 2 * amp * 2^-7 * |y| + 2e-3 everywhere (the flip, and one more rounding of the scaled term), and < 2 % of the elements differ at all.
+fp32 accumulate (wgrad) outputs: relative L2 <= 1e-5."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_F32_ACC, EPI_DGELU = 0, 1, 2, 3, 4
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+def _dgelu(x):
+    x = x.double()
+    k0, k1 = 0.7978845608028654, 0.044715
+    u = k0 * (x + k1 * x ** 3)
+    t = torch.tanh(u)
+    return (0.5 * (1 + t) + 0.5 * x * (1 - t * t) * k0 * (1 + 3 * k1 * x * x)).float()
+
+
+def _batched(M, cols, rpb, pad, dtype, gen, scale=1.0):
+    """A row-batched matrix: batches of `rpb` rows, `pad` junk rows between batches.  Returns (storage, Rows, dense)."""
+    from mixgrpo_amd.ops import Rows
+    nb = (M + rpb - 1) // rpb
+    store = (torch.randn(nb, rpb + pad, cols, generator=gen) * scale).to(dtype).cuda()
+    dense = store[:, :rpb].reshape(nb * rpb, cols)[:M]
+    return store, Rows(store, M, cols, rpb, (rpb + pad) * cols), dense
+
+
+def _close_bf16(out, ref, y=None, amp=0.0):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(out).all()
+    diff = (out - ref).abs()
+    tol = ref.abs() * 2.0 ** -7 + 2e-3
+    if y is not None:
+        tol = tol + 2 * torch.as_tensor(amp).float().cpu() * y.float().cpu().abs() * 2.0 ** -7
+    assert (diff <= tol).all(), f"max excess {(diff - tol).max().item()}"
+    assert (out != ref).float().mean().item() < 0.02
+
+
+# (M, N, K): persistent kernel needs ceil(M/256)*ceil(N/256) >= 192 and (N % 256 == 0 or N >= 2048)
+BIG = [(4096 + 37, 3072, 192), (6000, 2624, 128), (256 * 24, 2048, 64)]
+SMALL = [(200, 136, 192), (1000, 64, 256), (513, 1032, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", BIG + SMALL)
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_DGELU])
+@pytest.mark.parametrize("batched", [0, 1000, 1024])   # rows per batch: 1024 keeps the 16-byte epilogue, 1000 does not
+def test_gemm_epilogues(M, N, K, epi, batched):
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + epi)
+    rpb = batched if batched else 1 << 40
+    if batched:
+        _, A_rows, A = _batched(M, K, rpb, 3, torch.bfloat16, g, 0.5)
+        C_store, C_rows, C0 = _batched(M, N, rpb, 5, torch.bfloat16, g, 1.0)
+    else:
+        A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+        A_rows = Rows.of(A)
+        C_store = torch.randn(M, N, generator=g).bfloat16().cuda()
+        C_rows, C0 = Rows.of(C_store), C_store
+    C0 = C0.clone()
+    guard = C_store.clone()
+    W = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).bfloat16().cuda()
+    nb = (M + rpb - 1) // rpb if batched else 1
+    gate = (torch.randn(nb, N, generator=g)).bfloat16().cuda() if epi == EPI_GATE_RES else None
+    aux = None
+    if epi in (EPI_GELU, EPI_GATE_RES):
+        aux = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    elif epi == EPI_DGELU:
+        aux = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ops.gemm(A_rows, W, bias, C_rows, N, K, epi, gate=gate, gate_ld=N, aux=aux)
+    torch.cuda.synchronize()
+
+    y = (A.float() @ W.float().t() + bias.float()).bfloat16().float()          # the Linear's bf16 output
+    amp = 0.0
+    if epi == EPI_BIAS:
+        ref = y
+    elif epi == EPI_GELU:
+        ref, amp = _gelu(y), 1.2
+    elif epi == EPI_GATE_RES:
+        gsel = gate.float()[torch.arange(M, device="cuda") // rpb] if batched else gate.float()[0][None]
+        ref, amp = C0.float() + (gsel * y).bfloat16().float(), gsel.abs() + 0.01
+    else:
+        ref, amp = y * _dgelu(aux.float().cpu()).cuda(), 1.2
+    out = (C_store[:, :rpb].reshape(-1, N)[:M] if batched else C_store)
+    _close_bf16(out, ref.bfloat16(), y, amp)
+    if epi in (EPI_GELU, EPI_GATE_RES):
+        _close_bf16(aux, y.bfloat16())                                           # saved pre-activation / pre-gate output
+    if batched:                                                                  # padding rows between batches untouched
+        assert torch.equal(C_store[:, rpb:], guard[:, rpb:])
+
+
+@pytest.mark.parametrize("M,N,K,beta", [(3072, 4096 + 128, 320, 1.0), (2048 + 56, 3072, 128, 0.0), (300, 264, 192, 1.0)])
+def test_gemm_f32_accumulate(M, N, K, beta):
+    """wgrad form: C_f32 = beta * C + A @ W^T (no bias), both kernel families."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.5).bfloat16().cuda()
+    C = torch.randn(M, N, generator=g).cuda()
+    ref = beta * C.double() + A.double() @ W.double().t()
+    ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_F32_ACC, beta=beta)
+    torch.cuda.synchronize()
+    err = ((C.double() - ref).norm() / ref.norm()).item()
+    assert err < 1e-5, err
+
+
+def test_gemm_full_size_linearity():
+    """BASELINE-size check through a size-independent property: the GEMM is linear in A, so gemm(A1 + A2) with bf16-exact
+    operands equals gemm(A1) + gemm(A2) up to the output rounding (M = 8*4608 joint rows, FLUX d = 3072)."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    M, N, K = 8 * 4608, 3072, 3072
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # small integers / 8: sums are exact in bf16, products exact in fp32
+    A1 = (torch.randint(-4, 5, (M, K), generator=g, device="cuda").float() / 8).bfloat16()
+    A2 = (torch.randint(-4, 5, (M, K), generator=g, device="cuda").float() / 8).bfloat16()
+    W = (torch.randint(-2, 3, (N, K), generator=g, device="cuda").float() / 4).bfloat16()
+    outs = []
+    for A in (A1, A2, (A1.float() + A2.float()).bfloat16()):
+        C = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_F32_ACC, beta=0.0)
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0] + outs[1], outs[2])          # every partial sum is exactly representable: bit-exact
+    ref = A1[:512].float() @ W.float().t()
+    assert torch.equal(outs[0][:512], ref)
