@@ -165,9 +165,23 @@ def main():
                     fh.write(json.dumps(r) + "\n")
         ops.GEMM_PROFILE = None
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<EPI> (bf16 MFMA 128x128x64, all epilogues)",
+        # HBM traffic of the dominant kernel is a rocprofv3 PMC measurement (separate --pmc passes, FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950): it cannot be taken inside this process, so the committed summary
+        # of the round's PMC run is quoted, per launch of the profiled shape (see profiles/README.md)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_pmc_v3.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            traffic = pmc["traffic_bytes_per_launch"]
+            traffic_src = {"file": "profiles/r01_gemm_pmc_v3.json", "shape": pmc["shape"],
+                           "algorithmic_bytes_per_launch": pmc["algorithmic_bytes_per_launch"],
+                           "effective_clock_ghz": pmc["effective_clock_ghz"], "mfma_busy_frac": pmc["mfma_busy_frac"]}
+        roofline = {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI> (bf16 MFMA 256x256x64 persistent, all epilogues) "
+                                                "+ gemm_kernel<EPI> (128x128x64, small shapes)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n_launch,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "launches": n_launch,
                     "avg_launch_ms": round(tot_ms / max(1, n_launch), 4),
                     "gemm_share_of_step": round(tot_ms * 1e-3 / (dt / a.steps), 3),
                     "train_step_frac_of_peak": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
@@ -192,11 +206,30 @@ def main():
                            "algorithmic_pflop_per_image": round(flop_img / 1e15, 3)},
                 "images_per_sec_per_gpu": round(value / world, 5),
                 "mfma_frac_train_step": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+                "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4]} if last else None,
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _host_cores():
+    """Threads this process may really use: min(affinity, cgroup cpu quota, cpu_count) -- a GPU box reports all of
+    the host's logical cores in os.cpu_count() but grants a share of them."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
 
 
 def cpu_baseline(flop_img):
@@ -206,8 +239,8 @@ def cpu_baseline(flop_img):
     import torch
     from oracle import mmdit as OM
     from oracle import solver as OS
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    cores = _host_cores()
+    torch.set_num_threads(cores)
     cfg = OM.FluxConfig(num_layers=1, num_single_layers=1)
     P = OM.init_params(cfg, seed=0)
     N, L = 1024, 512
@@ -228,10 +261,11 @@ def cpu_baseline(flop_img):
     xs = torch.randn(1, 4096, 64, generator=g)
     v = torch.randn(1, 4096, 64, generator=g).bfloat16()
     sig = OS.sd3_time_shift(3.0, torch.linspace(1, 0, 26))
+    OS.flow_grpo_step(v, xs, 0.7, sig, 3, None)
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(5):
         OS.flow_grpo_step(v, xs, 0.7, sig, 3, None)
-    t_solver = (time.perf_counter() - t0) / 20
+    t_solver = (time.perf_counter() - t0) / 5
     sec_per_image = flop_img / rate + 25 * t_solver
     return {"value": round(1.0 / sec_per_image, 8), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle MMDiT forward d=3072, 1 double+1 single block, {N}+{L} tokens: {t_fwd:.2f}s = "

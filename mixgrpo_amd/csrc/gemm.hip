@@ -735,30 +735,6 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
   }
 }
 
-// L2 prefetch of the tile's side operand (residual rows of C, or the saved pre-activation): one 4-byte LDS-DMA per
-// 128-byte line into a junk LDS area (a DMA needs no destination register).  Issued with the last K-tile's DMA, it is
-// retired by that iteration's vmcnt(0) together with the next tile's first K-tile.
-template <int EPI>
-__device__ __forceinline__ void prefetch_side(const GemmArgs& g, char* junk, int wid, int lane, long m0, long n0) {
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) char gbl_char;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const long mu = m0 + (wu >> 2) * 128, nu = n0 + (wu & 3) * 64;
-  if (mu >= g.M || nu >= g.N) return;
-  const long bu = (uint32_t)mu / (uint32_t)g.c.rpb;
-  const char* base = EPI == EPI_BIAS_GATE_RES
-                         ? reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + nu) * 2
-                         : reinterpret_cast<const char*>(g.aux) + (mu * g.ldaux + nu) * 2;
-  const uint32_t ld2 = (uint32_t)((EPI == EPI_BIAS_GATE_RES ? g.c.ld : g.ldaux) * 2);
-  const int rmax = (int)(g.M - 1 - mu < 127 ? g.M - 1 - mu : 127);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = q * 64 + lane;
-    const uint32_t off = (uint32_t)(r < rmax ? r : rmax) * ld2;
-    __builtin_amdgcn_global_load_lds((gbl_char*)(base + off), (lds_char*)(junk + wu * 512 + q * 256), 4, 0, 0);
-  }
-}
-
 template <int EPI>
 __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, STAGE = 2 * TB, MT = 8, NTL = 4;
@@ -778,6 +754,7 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   int t_lin = xbeg + lane_in_xcd;
   if (t_lin >= xend) return;
 
+  const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar: LDS-DMA bases stay in SGPRs / M0
   const int lrow = tid >> 3, lkc = tid & 7;
   const int src_kc = swz(lrow, lkc);
   const int wrow = wperm(lrow);                    // W row (inside its 64-row group) that lands in LDS row lrow
@@ -813,7 +790,7 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   do {                                                                                                        \
     const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)(kt) * (BK * 2);                             \
     const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)(kt) * (BK * 2);                             \
-    const int lb_ = (buf) * STAGE + wid * 1024;                                                               \
+    const int lb_ = (buf) * STAGE + wu * 1024;                                                                \
     PGLDS_ONE(ab_, AO[0], lb_); PGLDS_ONE(ab_, AO[1], lb_ + RS * 128); PGLDS_ONE(ab_, AO[2], lb_ + 2 * RS * 128); \
     PGLDS_ONE(ab_, AO[3], lb_ + 3 * RS * 128);                                                                \
     PGLDS_ONE(wb_, WO[0], lb_ + TB); PGLDS_ONE(wb_, WO[1], lb_ + TB + RS * 128);                              \
@@ -842,53 +819,76 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) {
-        PGLDS_TILE(ao, wo, kt + 1, cur ^ 1);
-      } else {
-        if (has_next) PGLDS_TILE(nao, nwo, 0, cur ^ 1);
-        if ((EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_MULAUX) && g.rowwise_ok) {
-          int pl = lane, pw = wid;      // opaque copies: keeps the address arithmetic from being hoisted out of the K-loop
-          asm volatile("" : "+v"(pl), "+v"(pw));
-          prefetch_side<EPI>(g, smem + 2 * STAGE, pw, pl, m0, n0);
-        }
+      // ONE basic block per K-tile, in an explicit order: the 8 LDS-DMA pieces of the next K-tile (each costs the
+      // issuing wave 60-180 cycles) go out in pairs BEHIND the first four 8-MFMA groups instead of as a block at the
+      // top of the iteration, where both waves of a SIMD would sit in DMA issue together with the matrix pipe idle.
+      // The last iteration fetches the next tile's first K-tile (or, for the last tile, re-fetches its own first
+      // K-tile into the idle buffer) so the body needs no branch.
+      const bool lastk = kt + 1 == nkt;
+      const long kb = lastk ? 0 : (long)(kt + 1) * (BK * 2);
+      const char* ab_ = reinterpret_cast<const char*>(g.A) + kb;
+      const char* wb_ = reinterpret_cast<const char*>(g.W) + kb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ao[k] = lastk ? nao[k] : ao[k];
+        wo[k] = lastk ? nwo[k] : wo[k];
       }
+      const int lb_ = (cur ^ 1) * STAGE + wu * 1024;
       const char* sa = smem + cur * STAGE;
       const char* sw = sa + TB;
-      // all 24 fragment reads of the K-tile in program order, then the 64 MFMAs; the scheduler is told to issue the
-      // reads TWO 8-MFMA groups ahead of their consumers (hipcc otherwise sinks every read next to its MFMA)
       s16x8 fa[2][MT], fw[2][NTL];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-          const int rw_ = wn * 64 + t * 16 + fr;
-          fw[ks][t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, ks * 4 + fq) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const int ra_ = wm * 128 + t * 16 + fr;
-          fa[ks][t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, ks * 4 + fq) * 16);
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-#pragma unroll
-          for (int i = 0; i < NTL; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);     // groups 0,1,2 (6 + 2 + 2 reads)
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 3
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // group 4 (second k-step: 4 W + 2 A fragments)
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 5
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 6
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // group 7
-      __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+#define RD_W(ks, t)                                                                                        \
+  do {                                                                                                     \
+    const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
+    fw[ks][t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, (ks) * 4 + fq) * 16);          \
+  } while (0)
+#define RD_A(ks, t)                                                                                        \
+  do {                                                                                                     \
+    const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
+    fa[ks][t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);          \
+  } while (0)
+#define MMA_GROUP(ks, gq)                                                                                  \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
+  } while (0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+      RD_W(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3);
+      RD_A(0, 0); RD_A(0, 1); RD_A(0, 2); RD_A(0, 3); RD_A(0, 4); RD_A(0, 5);
+      PIN();
+      MMA_GROUP(0, 0);
+      PIN();
+      RD_A(0, 6); RD_A(0, 7);
+      PGLDS_ONE(ab_, ao[0], lb_); PGLDS_ONE(ab_, ao[1], lb_ + RS * 128);
+      PIN();
+      MMA_GROUP(0, 1);
+      PIN();
+      RD_W(1, 0); RD_W(1, 1); RD_W(1, 2); RD_W(1, 3); RD_A(1, 0); RD_A(1, 1);
+      PGLDS_ONE(ab_, ao[2], lb_ + 2 * RS * 128); PGLDS_ONE(ab_, ao[3], lb_ + 3 * RS * 128);
+      PIN();
+      MMA_GROUP(0, 2);
+      PIN();
+      RD_A(1, 2); RD_A(1, 3);
+      PGLDS_ONE(wb_, wo[0], lb_ + TB); PGLDS_ONE(wb_, wo[1], lb_ + TB + RS * 128);
+      PIN();
+      MMA_GROUP(0, 3);
+      PIN();
+      RD_A(1, 4); RD_A(1, 5);
+      PGLDS_ONE(wb_, wo[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, wo[3], lb_ + TB + 3 * RS * 128);
+      PIN();
+      MMA_GROUP(1, 0);
+      PIN();
+      RD_A(1, 6); RD_A(1, 7);
+      PIN();
+      MMA_GROUP(1, 1);
+      MMA_GROUP(1, 2);
+      MMA_GROUP(1, 3);
+      PIN();
+#undef RD_W
+#undef RD_A
+#undef MMA_GROUP
+#undef PIN
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
@@ -922,14 +922,14 @@ int launch(const GemmArgs& g, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 4;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA, 4: persistent
   if (big && mode == 4 && g.span32) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    gemm_persist_kernel<EPI><<<grid, 512, 131072 + 4096, st>>>(g);   // + junk area of prefetch_side
+    gemm_persist_kernel<EPI><<<grid, 512, 131072, st>>>(g);
   } else if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   else if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
   else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);

@@ -320,7 +320,10 @@ class FluxTransformer2DModel(torch.nn.Module):
             return Rows(t, w.B * w.L, width, w.L, w.S * width)
         return Rows(t[0, w.L:], w.B * w.N, width, w.N, w.S * width)
 
-    def _double_block(self, i, w, st, cos, sin, save=None, mods_in=None):
+    def _double_block(self, i, w, st, cos, sin, save=None, mods_in=None, keep=None, replay=False):
+        """`save`: keep the block's intermediates for the backward walk (recompute pass).  `keep`: per-block buffers
+        {O, lse, y_attn, y_ff, x_mid} written by the training forward; with `replay` the recompute pass reads them
+        back instead of re-running attention and the two output projections (to_out / ff.net.2)."""
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"transformer_blocks.{i}"
         B = w.B
@@ -347,33 +350,48 @@ class FluxTransformer2DModel(torch.nn.Module):
             ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
                              w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
-        ops.attn_fwd(w.Q, w.K, w.Vt, w.O, w.lse if save is not None else None, B, H, w.S, w.Sp, d, w.S * d,
-                     1.0 / math.sqrt(cfg.attention_head_dim))
+        if replay:
+            w.O.copy_(keep["O"])
+            w.lse.copy_(keep["lse"])
+        else:
+            ops.attn_fwd(w.Q, w.K, w.Vt, w.O, keep["lse"] if keep is not None else (w.lse if save is not None else None),
+                         B, H, w.S, w.Sp, d, w.S * d, 1.0 / math.sqrt(cfg.attention_head_dim))
+            if keep is not None:
+                keep["O"].copy_(w.O)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m = mods[name]
             M = B * rows
+            sl = slice(row0[name], row0[name] + M)
             Xs = self._stream_rows(w.X, w, name, d)
             Os = self._stream_rows(w.O, w, name, d)
-            nrm = (w.nrm if save is None else save["nrm2"])[row0[name]:row0[name] + M]
-            hid = w.hid[row0[name]:row0[name] + M]
+            nrm = (w.nrm if save is None else save["nrm2"])[sl]
+            hid = w.hid[sl]
             aux1 = aux2 = hpre = None
+            if keep is not None and not replay:
+                aux1, aux2 = keep["y_attn"][sl], keep["y_ff"][sl]
+            elif save is not None:
+                aux1, aux2 = save["y_attn"][sl], save["y_ff"][sl]
             if save is not None:
-                aux1 = save["y_attn"][row0[name]:row0[name] + M]
-                aux2 = save["y_ff"][row0[name]:row0[name] + M]
-                hpre = save["hid_pre"][row0[name]:row0[name] + M]
-            ops.gemm(Os, self.W(f"{p}.attn.{outn}.weight"), self.W(f"{p}.attn.{outn}.bias"), Xs, d, d,
-                     EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=6 * d, aux=aux1)
-            if save is not None:
-                (save["x_mid"][:, :w.L] if name == "txt" else save["x_mid"][:, w.L:]).copy_(
-                    w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
-            ops.ln_modulate(Xs, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
+                hpre = save["hid_pre"][sl]
+            xs_mid = Xs
+            if replay:
+                xs_mid = self._stream_rows(keep["x_mid"], w, name, d)       # saved: no to_out GEMM in the recompute
+            else:
+                ops.gemm(Os, self.W(f"{p}.attn.{outn}.weight"), self.W(f"{p}.attn.{outn}.bias"), Xs, d, d,
+                         EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=6 * d, aux=aux1)
+                xm = keep["x_mid"] if keep is not None else (save["x_mid"] if save is not None else None)
+                if xm is not None:
+                    (xm[:, :w.L] if name == "txt" else xm[:, w.L:]).copy_(w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
+            ops.ln_modulate(xs_mid, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
             ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
                      Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
-            ops.gemm(Rows.of(hid), self.W(f"{p}.{ffn}.net.2.weight"), self.W(f"{p}.{ffn}.net.2.bias"), Xs, d, 4 * d,
-                     EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
+            if not replay:                                                   # y_ff saved: no ff.net.2 GEMM in the recompute
+                ops.gemm(Rows.of(hid), self.W(f"{p}.{ffn}.net.2.weight"), self.W(f"{p}.{ffn}.net.2.bias"), Xs, d, 4 * d,
+                         EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
         return mods
 
-    def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None):
+    def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None, keep=None, replay=False):
+        """`keep` / `replay`: as in `_double_block`, with per-block buffers {O, lse, y_attn}."""
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"single_transformer_blocks.{i}"
         B, S = w.B, w.S
@@ -396,10 +414,17 @@ class FluxTransformer2DModel(torch.nn.Module):
         ops.qk_norm_rope(w.qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
                          w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
-        ops.attn_fwd(w.Q, w.K, w.Vt, w.cat, w.lse if save is not None else None, B, H, S, w.Sp, 5 * d, S * 5 * d,
-                     1.0 / math.sqrt(cfg.attention_head_dim))
+        if replay:                                   # attention output and proj_out result were kept by the forward
+            w.cat[:, :, :d].copy_(keep["O"])
+            w.lse.copy_(keep["lse"])
+            return m
+        ops.attn_fwd(w.Q, w.K, w.Vt, w.cat, keep["lse"] if keep is not None else (w.lse if save is not None else None),
+                     B, H, S, w.Sp, 5 * d, S * 5 * d, 1.0 / math.sqrt(cfg.attention_head_dim))
+        if keep is not None:
+            keep["O"].copy_(w.cat[:, :, :d])
+        aux = keep["y_attn"] if keep is not None else (None if save is None else save["y_attn"])
         ops.gemm(Rows.of(cat2), self.W(f"{p}.proj_out.weight"), self.W(f"{p}.proj_out.bias"), Xa, d, 5 * d,
-                 EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=3 * d, aux=None if save is None else save["y_attn"])
+                 EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=3 * d, aux=aux)
         return m
 
     def _embed(self, w, hidden_states, encoder_hidden_states):

@@ -16,6 +16,11 @@ from . import ops
 from .ops import BF16, F32, Rows, EPI_BIAS, EPI_BIAS_GATE_RES, EPI_DGELU, EPI_F32_ACC
 
 
+import os
+
+KEEP_ACTS = os.environ.get("MGX_KEEP_ACTS", "1") != "0"
+
+
 def _pad64(n):
     return (n + 63) // 64 * 64
 
@@ -30,8 +35,20 @@ class _Train:
         e = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=device)
         z = lambda *shape, dtype=BF16: torch.zeros(*shape, dtype=dtype, device=device)
         nblk = cfg.num_layers + cfg.num_single_layers
-        self.block_in = e(nblk, B, S, d)          # the only activations kept by the forward
+        self.block_in = e(nblk, B, S, d)          # block inputs: the recompute pass starts from these
         self.x_final = e(B, S, d)
+        # Selective activation saving (288 GB HBM: no parameter sharding, so there is room): the attention output + LSE
+        # and the pre-gate outputs of the projections that END a residual branch are kept per block (4 x 28 MB per
+        # sample and double block, 2 x per single block), so the recompute pass skips attention and those GEMMs:
+        # 5/12 of a block's linear FLOPs and all of its attention FLOPs.  MGX_KEEP_ACTS=0 restores full recompute.
+        self.keep = None
+        if KEEP_ACTS:
+            self.keep = []
+            for b in range(nblk):
+                k = dict(O=e(B, S, d), lse=e(B, H, S, dtype=F32), y_attn=e(M, d))
+                if b < cfg.num_layers:
+                    k.update(y_ff=e(M, d), x_mid=e(B, S, d))
+                self.keep.append(k)
         self.save = dict(nrm1=e(M, d), nrm2=e(M, d), y_attn=e(M, d), y_ff=e(M, d), hid_pre=e(M, 4 * d),
                          x_mid=e(B, S, d), V=e(B, H, S, hd), Qt=z(B, H, hd, Sp), Kt=z(B, H, hd, Sp))
         self.dX = e(B, S, d)
@@ -69,11 +86,11 @@ class FluxFunction(torch.autograd.Function):
         blk = 0
         for i in range(cfg.num_layers):
             tr.block_in[blk].copy_(w.X)
-            mods.append(model._double_block(i, w, st, cos, sin))
+            mods.append(model._double_block(i, w, st, cos, sin, keep=tr.keep[blk] if tr.keep else None))
             blk += 1
         for i in range(cfg.num_single_layers):
             tr.block_in[blk].copy_(w.X)
-            mods.append(model._single_block(i, w, st, cos, sin))
+            mods.append(model._single_block(i, w, st, cos, sin, keep=tr.keep[blk] if tr.keep else None))
             blk += 1
         tr.x_final.copy_(w.X)
         out, e = model._head(w, st)
@@ -139,7 +156,8 @@ def _backward(model, w, tr, sv, dout):
     store = model.store
     g32 = store.ensure_grad()
     dst = torch.zeros(B, d, dtype=BF16, device=dev)        # grad wrt st = silu(temb), summed over all users
-    save = tr.save
+    save0 = tr.save
+    save = save0
     row0 = {"txt": 0, "img": B * L}
 
     def srows(t, which, width):
@@ -167,7 +185,9 @@ def _backward(model, w, tr, sv, dout):
         p = f"single_transformer_blocks.{i}"
         m = sv["mods"][blk]
         w.X.copy_(tr.block_in[blk])
-        model._single_block(i, w, st_, cos, sin, save=save, mod_in=m)
+        kept = tr.keep[blk] if tr.keep else None
+        save = dict(save0, y_attn=kept["y_attn"]) if kept else save0
+        model._single_block(i, w, st_, cos, sin, save=save, mod_in=m, keep=kept, replay=kept is not None)
         dmod = torch.empty(B, 3 * d, dtype=BF16, device=dev)
         x_in = Rows(tr.block_in[blk], M, d, S, S * d)
         dXr = Rows(tr.dX, M, d, S, S * d)
@@ -210,7 +230,9 @@ def _backward(model, w, tr, sv, dout):
         p = f"transformer_blocks.{i}"
         mods = sv["mods"][i]
         w.X.copy_(tr.block_in[i])
-        model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods)
+        kept = tr.keep[i] if tr.keep else None
+        save = dict(save0, y_attn=kept["y_attn"], y_ff=kept["y_ff"], x_mid=kept["x_mid"]) if kept else save0
+        model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods, keep=kept, replay=kept is not None)
         dmods = {k: torch.empty(B, 6 * d, dtype=BF16, device=dev) for k in ("img", "txt")}
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m, dm = mods[name], dmods[name]

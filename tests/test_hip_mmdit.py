@@ -140,6 +140,27 @@ def test_backward_vs_oracle_autograd(B, hg, wg, L):
     assert rel_err(m.store.view(g, k0), 2 * Pg[k0].grad) < 4e-2
 
 
+def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
+    """The training forward keeps the attention output / LSE and the pre-gate outputs of to_out, ff.net.2 and proj_out so
+    that the recompute pass skips attention and those GEMMs (flux_backward._Train.keep).  The kept values are the very
+    values a recompute would produce, so the gradients must be bit-identical to full block recompute."""
+    from mixgrpo_amd import flux_backward as FB
+    grads = []
+    for keep in (True, False):
+        monkeypatch.setattr(FB, "KEEP_ACTS", keep)
+        ocfg, P, m = build_pair(small_cfg(2, 2))
+        x, ehs, pooled, ids, tids, t, gd = make_inputs(2, 6, 10, 24, seed=3)
+        R = torch.randn(2, 60, 64, generator=torch.Generator().manual_seed(9)).cuda()
+        m.train()
+        out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
+        (out.float() * R).sum().backward()
+        w = next(iter(m._work.values()))
+        assert (w.train.keep is not None) == keep
+        grads.append((out.detach().clone(), m.store.g32.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert torch.equal(grads[0][1], grads[1][1])
+
+
 def test_attention_backward_vs_torch():
     from mixgrpo_amd import ops
     B, H, S = 1, 2, 700
