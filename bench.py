@@ -207,6 +207,8 @@ def main():
                 "images_per_sec_per_gpu": round(value / world, 5),
                 "mfma_frac_train_step": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
                 "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                "hbm_reserved_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
+                "hbm_free_gib": round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1),
                 "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4]} if last else None,
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -1,0 +1,69 @@
+"""Checkpoint format of the reference trainer + the resume it lacks.
+
+`save_checkpoint(transformer, rank, output_dir, step, epoch)` mirrors fastvideo/utils/checkpoint.py:65-88: rank 0 writes
+`{output_dir}/checkpoint-{step}-{epoch}/diffusion_pytorch_model.safetensors` (diffusers key names, fp32 master weights)
+and `config.json` (the transformer's config without `dtype`), which `fastvideo/sample/sample_flux.py:28-30,464-465`
+loads with `load_state_dict(strict=True)`.  Under replica data parallelism every rank holds the full weights, so the
+reference's FSDP full-state-dict gather (:67-72) has no counterpart: rank 0 writes its own copy.
+
+`save_resume_state` / `load_resume_state` add what the reference cannot do (train_grpo_flux.py:781-783 only parses
+a step number from `--resume_from_checkpoint` and never restores anything): the AdamW moments and step count, the LR
+schedule position, the SDE-window scheduler (`GRPOTrainingStates`) and the global step, next to the weights.
+"""
+import dataclasses
+import json
+import os
+
+import torch
+
+from .dist_utils import main_print
+
+
+def save_checkpoint(transformer, rank, output_dir, step, epoch):
+    main_print(f"--> saving checkpoint at step {step}")
+    save_dir = os.path.join(output_dir, f"checkpoint-{step}-{epoch}")
+    if rank <= 0:
+        transformer.save_pretrained(save_dir)
+    main_print(f"--> checkpoint saved at step {step}")
+    return save_dir
+
+
+def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, global_step=0, rank=0):
+    """Writes `optimizer.safetensors` (m, v: flat fp32 in the parameter store's order) and `trainer_state.json`."""
+    if rank > 0:
+        return
+    from safetensors.torch import save_file
+    os.makedirs(save_dir, exist_ok=True)
+    sd = optimizer.state_dict()
+    save_file({"m": sd["m"].detach().cpu(), "v": sd["v"].detach().cpu()}, os.path.join(save_dir, "optimizer.safetensors"))
+    state = {"global_step": int(global_step), "optimizer_step": int(sd["step"]), "lr": float(sd["lr"]),
+             "base_lr": float(optimizer.base_lr)}
+    if lr_scheduler is not None:
+        state["lr_scheduler"] = {"n": int(lr_scheduler.n), "warmup": int(lr_scheduler.warmup),
+                                 "base": [float(b) for b in lr_scheduler.base]}
+    if grpo_states is not None:
+        state["grpo_states"] = dataclasses.asdict(grpo_states)
+        state["grpo_states"]["init_timestep"] = int(grpo_states.init_timestep)
+    with open(os.path.join(save_dir, "trainer_state.json"), "w") as f:
+        json.dump(state, f, indent=2)
+
+
+def load_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None):
+    """Restores what `save_resume_state` wrote (weights are loaded separately with `from_pretrained` /
+    `load_state_dict`).  Returns the global step to continue from."""
+    from safetensors.torch import load_file
+    with open(os.path.join(save_dir, "trainer_state.json")) as f:
+        state = json.load(f)
+    mv = load_file(os.path.join(save_dir, "optimizer.safetensors"))
+    if mv["m"].numel() != optimizer.m.numel():
+        raise ValueError(f"optimizer state has {mv['m'].numel()} elements, the model's flat store {optimizer.m.numel()}")
+    optimizer.load_state_dict({"step": state["optimizer_step"], "m": mv["m"], "v": mv["v"], "lr": state["lr"]})
+    if lr_scheduler is not None and "lr_scheduler" in state:
+        lr_scheduler.n = state["lr_scheduler"]["n"]
+        lr_scheduler.warmup = state["lr_scheduler"]["warmup"]
+        lr_scheduler.base = list(state["lr_scheduler"]["base"])
+        lr_scheduler._apply()
+    if grpo_states is not None and "grpo_states" in state:
+        for k, v in state["grpo_states"].items():
+            setattr(grpo_states, k, v)
+    return state["global_step"]

@@ -1,0 +1,28 @@
+"""Host-side schedule of the mixed-model inference sampler (mixgrpo_amd/sample_flux.py; reference
+fastvideo/sample/sample_flux.py:249-264) against the oracle restatement and hand-computed anchors.  The scheduler
+itself lives in diffusers (absent offline): parity unpinned, see oracle/sampler.py."""
+import math
+
+import torch
+
+from mixgrpo_amd import sample_flux as SF
+from oracle import sampler as OS
+
+
+def test_calculate_shift_anchors():
+    assert abs(SF.calculate_shift(256) - 0.5) < 1e-12           # base_image_seq_len -> base_shift
+    assert abs(SF.calculate_shift(4096) - 1.15) < 1e-12         # max_image_seq_len (1024^2) -> max_shift
+    assert abs(SF.calculate_shift(2025) - OS.calculate_shift(2025)) < 1e-15   # 720^2
+
+
+def test_sigma_schedule_matches_oracle_and_formula():
+    for T, n in ((28, 4096), (50, 2025), (6, 64)):
+        sig, ts = SF.flow_match_sigmas(T, SF.calculate_shift(n))
+        ref = OS.sigmas_for(T, n)
+        assert torch.equal(sig, ref)
+        assert sig.shape == (T + 1,) and sig[0] == 1.0 and sig[-1] == 0.0
+        assert torch.all(sig[:-1] > sig[1:])                    # strictly decreasing
+        assert torch.equal(ts, sig[:-1] * 1000.0)
+        mu = SF.calculate_shift(n)
+        s_last = 1.0 / T
+        assert abs(sig[T - 1].item() - math.exp(mu) / (math.exp(mu) + (1 / s_last - 1))) < 1e-6
