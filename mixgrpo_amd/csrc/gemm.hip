@@ -797,6 +797,33 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     PGLDS_ONE(wb_, WO[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, WO[3], lb_ + TB + 3 * RS * 128);           \
   } while (0)
 
+  // fragment registers live across K-tiles (the head of a K-tile is read during the tail of its predecessor)
+  s16x8 fa[2][MT], fw[2][NTL];
+#define RD_W(SW, ks, t)                                                                                    \
+  do {                                                                                                     \
+    const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
+    fw[ks][t] = *reinterpret_cast<const s16x8*>((SW) + rw_ * 128 + swz(rw_, (ks) * 4 + fq) * 16);         \
+  } while (0)
+#define RD_A(SA, ks, t)                                                                                    \
+  do {                                                                                                     \
+    const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
+    fa[ks][t] = *reinterpret_cast<const s16x8*>((SA) + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);         \
+  } while (0)
+#define HEAD_READS(STG)                                                                                    \
+  do {                                                                                                     \
+    const char* sa_ = (STG);                                                                               \
+    const char* sw_ = sa_ + TB;                                                                            \
+    RD_W(sw_, 0, 0); RD_W(sw_, 0, 1); RD_W(sw_, 0, 2); RD_W(sw_, 0, 3);                                    \
+    RD_A(sa_, 0, 0); RD_A(sa_, 0, 1); RD_A(sa_, 0, 2); RD_A(sa_, 0, 3); RD_A(sa_, 0, 4); RD_A(sa_, 0, 5);  \
+  } while (0)
+#define MMA_GROUP(ks, gq)                                                                                  \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
+  } while (0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+
   TILE_COORDS(t_lin, m0, n0);
   TILE_OFFS(m0, n0, ao, wo);
   PGLDS_TILE(ao, wo, 0, 0);
@@ -819,11 +846,12 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nkt; ++kt) {
-      // ONE basic block per K-tile, in an explicit order: the 8 LDS-DMA pieces of the next K-tile (each costs the
-      // issuing wave 60-180 cycles) go out in pairs BEHIND the first four 8-MFMA groups instead of as a block at the
-      // top of the iteration, where both waves of a SIMD would sit in DMA issue together with the matrix pipe idle.
-      // The last iteration fetches the next tile's first K-tile (or, for the last tile, re-fetches its own first
-      // K-tile into the idle buffer) so the body needs no branch.
+      // One straight-line block per K-tile, in an explicit order (PIN = sched_barrier(0)): fragment reads two 8-MFMA
+      // groups ahead of their use; the 8 LDS-DMA pieces of the next K-tile (60-180 issue cycles each) in pairs behind
+      // the first four groups instead of as a block at the top of the iteration; the last iteration fetches the next
+      // tile's first K-tile (or, for the last tile, re-fetches its own first K-tile into the idle buffer), so the body
+      // needs no branch.  (Measured and dropped: the K-tile barrier moved before the last two groups with the next
+      // K-tile's head reads issued right behind it -- 5-9 % slower in a same-box A/B.)
       const bool lastk = kt + 1 == nkt;
       const long kb = lastk ? 0 : (long)(kt + 1) * (BK * 2);
       const char* ab_ = reinterpret_cast<const char*>(g.A) + kb;
@@ -836,59 +864,37 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       const int lb_ = (cur ^ 1) * STAGE + wu * 1024;
       const char* sa = smem + cur * STAGE;
       const char* sw = sa + TB;
-      s16x8 fa[2][MT], fw[2][NTL];
-#define RD_W(ks, t)                                                                                        \
-  do {                                                                                                     \
-    const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
-    fw[ks][t] = *reinterpret_cast<const s16x8*>(sw + rw_ * 128 + swz(rw_, (ks) * 4 + fq) * 16);          \
-  } while (0)
-#define RD_A(ks, t)                                                                                        \
-  do {                                                                                                     \
-    const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
-    fa[ks][t] = *reinterpret_cast<const s16x8*>(sa + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);          \
-  } while (0)
-#define MMA_GROUP(ks, gq)                                                                                  \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
-      _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
-  } while (0)
-#define PIN() __builtin_amdgcn_sched_barrier(0)
-      RD_W(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3);
-      RD_A(0, 0); RD_A(0, 1); RD_A(0, 2); RD_A(0, 3); RD_A(0, 4); RD_A(0, 5);
+      HEAD_READS(sa);
       PIN();
       MMA_GROUP(0, 0);
       PIN();
-      RD_A(0, 6); RD_A(0, 7);
+      RD_A(sa, 0, 6); RD_A(sa, 0, 7);
       PGLDS_ONE(ab_, ao[0], lb_); PGLDS_ONE(ab_, ao[1], lb_ + RS * 128);
       PIN();
       MMA_GROUP(0, 1);
       PIN();
-      RD_W(1, 0); RD_W(1, 1); RD_W(1, 2); RD_W(1, 3); RD_A(1, 0); RD_A(1, 1);
+      RD_W(sw, 1, 0); RD_W(sw, 1, 1); RD_W(sw, 1, 2); RD_W(sw, 1, 3); RD_A(sa, 1, 0); RD_A(sa, 1, 1);
       PGLDS_ONE(ab_, ao[2], lb_ + 2 * RS * 128); PGLDS_ONE(ab_, ao[3], lb_ + 3 * RS * 128);
       PIN();
       MMA_GROUP(0, 2);
       PIN();
-      RD_A(1, 2); RD_A(1, 3);
+      RD_A(sa, 1, 2); RD_A(sa, 1, 3);
       PGLDS_ONE(wb_, wo[0], lb_ + TB); PGLDS_ONE(wb_, wo[1], lb_ + TB + RS * 128);
       PIN();
       MMA_GROUP(0, 3);
       PIN();
-      RD_A(1, 4); RD_A(1, 5);
+      RD_A(sa, 1, 4); RD_A(sa, 1, 5);
       PGLDS_ONE(wb_, wo[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, wo[3], lb_ + TB + 3 * RS * 128);
       PIN();
       MMA_GROUP(1, 0);
       PIN();
-      RD_A(1, 6); RD_A(1, 7);
+      RD_A(sa, 1, 6); RD_A(sa, 1, 7);
       PIN();
       MMA_GROUP(1, 1);
+      PIN();
       MMA_GROUP(1, 2);
       MMA_GROUP(1, 3);
       PIN();
-#undef RD_W
-#undef RD_A
-#undef MMA_GROUP
-#undef PIN
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
@@ -909,6 +915,11 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #undef TILE_OFFS
 #undef PGLDS_ONE
 #undef PGLDS_TILE
+#undef RD_W
+#undef RD_A
+#undef HEAD_READS
+#undef MMA_GROUP
+#undef PIN
 }
 
 template <int EPI>
