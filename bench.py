@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--train-microbatch", type=int, default=6)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-dead-backward", action="store_true",
+                    help="do not execute the backward passes of the G %% accum leftover samples, whose gradients the "
+                         "reference computes and discards (identical outputs; NOT the default, NOT the headline number)")
     ap.add_argument("--gemm-shapes", default=None, help="write the per-shape GEMM time table of the roofline step here")
     a = ap.parse_args()
 
@@ -87,7 +90,8 @@ def main():
     opt = FusedAdamW(model, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     sched = ConstantWithWarmup(opt, 0)
     args = TG.default_args(h=wl["h"], w=wl["w"], sampling_steps=wl["sampling_steps"], num_generations=wl["num_generations"],
-                           gradient_accumulation_steps=wl["gradient_accumulation_steps"], train_microbatch=a.train_microbatch)
+                           gradient_accumulation_steps=wl["gradient_accumulation_steps"], train_microbatch=a.train_microbatch,
+                           skip_dead_backward=a.skip_dead_backward)
     T, G, W = args.sampling_steps, args.num_generations, wl["window"]
     states = GRPOTrainingStates(iters_per_group=25, group_size=W, max_timesteps=T - 2, prog_overlap=True,
                                 prog_overlap_step=1, roll_back=True)
@@ -140,7 +144,10 @@ def main():
     images = world * G * a.steps
     value = images / dt
     f_fwd = flops_per_forward(cfg, n_img, L)
-    flop_img = (T + 3 * W) * f_fwd                      # algorithmic (recompute not counted), SURVEY.md 8d
+    # algorithmic FLOPs per image (recompute not counted); with --skip-dead-backward the G % accum leftover
+    # images run no backward, and are counted accordingly
+    dead = (G % args.gradient_accumulation_steps) if a.skip_dead_backward else 0
+    flop_img = (T + 3 * W - 2.0 * W * dead / G) * f_fwd
 
     roofline = None
     if not a.no_roofline and rank == 0:
@@ -203,6 +210,7 @@ def main():
                            "sampling_steps": T, "sde_window": last[1] if last else None, "group_size": G,
                            "grad_accum": args.gradient_accumulation_steps, "global_batch": world * G,
                            "seq_len": n_img + L, "parallelism": f"dp{world}", "train_microbatch": a.train_microbatch,
+                           "skip_dead_backward": bool(a.skip_dead_backward),
                            "algorithmic_pflop_per_image": round(flop_img / 1e15, 3)},
                 "images_per_sec_per_gpu": round(value / world, 5),
                 "mfma_frac_train_step": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -236,23 +244,24 @@ def _host_cores():
 
 def cpu_baseline(flop_img):
     """The CPU oracle (a port: kind "port") timed on this box's host cores on a bounded sample of the workload:
-    one full-width (d=3072, 24 heads) MMDiT forward with 1 double + 1 single block on 1024 image + 512 text
-    tokens, and one full-size solver step; images/s is EXTRAPOLATED by algorithmic FLOPs to the 25/4 train step."""
+    one full-width (d=3072, 24 heads), full-sequence (4096 image + 512 text tokens) MMDiT forward with 2 double + 2
+    single blocks (~5 TFLOP, 10-30 s of CPU work), and a full-size solver step; images/s is EXTRAPOLATED by algorithmic
+    FLOPs to the 25/4 train step."""
     import torch
     from oracle import mmdit as OM
     from oracle import solver as OS
     cores = _host_cores()
     torch.set_num_threads(cores)
-    cfg = OM.FluxConfig(num_layers=1, num_single_layers=1)
+    cfg = OM.FluxConfig(num_layers=2, num_single_layers=2)
     P = OM.init_params(cfg, seed=0)
-    N, L = 1024, 512
+    N, L = 4096, 512
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, N, 64, generator=g)
     ehs = 0.1 * torch.randn(1, L, 4096, generator=g)
     pooled = torch.randn(1, 768, generator=g)
-    ids = torch.zeros(32, 32, 3)
-    ids[..., 1] += torch.arange(32)[:, None]
-    ids[..., 2] += torch.arange(32)[None]
+    ids = torch.zeros(64, 64, 3)
+    ids[..., 1] += torch.arange(64)[:, None]
+    ids[..., 2] += torch.arange(64)[None]
     ids = ids.reshape(N, 3)
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -270,7 +279,7 @@ def cpu_baseline(flop_img):
     t_solver = (time.perf_counter() - t0) / 5
     sec_per_image = flop_img / rate + 25 * t_solver
     return {"value": round(1.0 / sec_per_image, 8), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle MMDiT forward d=3072, 1 double+1 single block, {N}+{L} tokens: {t_fwd:.2f}s = "
+            "sample": f"oracle MMDiT forward d=3072, 2 double+2 single blocks, {N}+{L} tokens: {t_fwd:.2f}s = "
                       f"{rate / 1e12:.3f} TFLOP/s; full-size solver step {t_solver * 1e3:.2f} ms; images/s extrapolated "
                       f"by algorithmic FLOPs to the T=25/W=4 train step ({flop_img / 1e15:.3f} PFLOP/image)"}
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 // NW waves per workgroup (QB = 32*NW queries).  NW = 4 puts two independent workgroups on a CU (64 KiB LDS each): their
 // barriers are unrelated, so one workgroup's softmax VALU phase runs under the other's MFMA phase instead of the two
 // waves of a SIMD marching in lockstep.
-template <int NW>
+template <int NW, bool DEFER>
 __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   constexpr int QB = QW * NW;
   constexpr int NCH = 1024 / (NW * 64);   // 16-byte chunks per thread per operand tile
@@ -172,10 +172,26 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * g.scale_log2e);   // m_run = -inf on the first tile -> 0
-    const float mc = m_new * g.scale_log2e;
-    m_run = m_new;
+    // Deferred rescale (DEFER): the running maximum is only raised -- and O, l rescaled -- when some row of the wave
+    // has outgrown it by more than 2^DEFER_LOG2; otherwise the stale maximum is kept and this tile's P may reach
+    // 2^DEFER_LOG2 instead of 1 (fp32 row sums and accumulators, bf16 P: the relative precision is unchanged).  The
+    // decision is taken BEFORE this tile's P is exponentiated and after the previous tile's P V has been issued, so
+    // everything still at the old scale (O, l) is rescaled exactly once and nothing at the new scale is.  It saves the
+    // 64 v_mul of the O rescale (a quarter of the tile's VALU work) on almost every tile.
+    constexpr float DEFER_LOG2 = 6.0f;
+    bool rescale = true;
+    if (DEFER) rescale = __builtin_amdgcn_ballot_w64((mx - m_run) * g.scale_log2e > DEFER_LOG2) != 0;   // -inf run max: true
+    float alpha = 1.0f;
+    if (rescale) {
+      const float m_new = fmaxf(m_run, mx);
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * g.scale_log2e);   // m_run = -inf on the first tile -> 0
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    }
+    const float mc = m_run * g.scale_log2e;
     float psum = 0.f;
     uint32_t pb[2][8];   // P^T as bf16 pairs: B-operand fragments, k-step s uses regs 8s..8s+7
 #pragma unroll
@@ -188,10 +204,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
         pb[kb][i >> 1] = pack_bf16(p0, p1);
       }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
 
     // ---- O^T += Vt P^T : A = Vt[d = 32*dt + r][keys in the accumulator's permuted order]
 #pragma unroll
@@ -258,11 +270,13 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
   g.scale_log2e = scale * 1.4426950408889634f;
   static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 8;
-  if (nw == 8) {
-    attn_fwd_kernel<8><<<cdiv(S, 256) * H * B, 512, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
-  } else {
-    attn_fwd_kernel<4><<<cdiv(S, 128) * H * B, 256, 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream>>>(g);
-  }
+  static const int defer = getenv("MGX_ATTN_DEFER") ? atoi(getenv("MGX_ATTN_DEFER")) : 1;
+  const int lds = 2 * (K_TILE_BYTES + V_TILE_BYTES);
+  hipStream_t st = (hipStream_t)stream;
+  if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
+  else if (nw == 8) attn_fwd_kernel<8, false><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
+  else if (defer) attn_fwd_kernel<4, true><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
+  else attn_fwd_kernel<4, false><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -39,7 +39,7 @@ def default_args(**kw):
              timestep_fraction=0.6, frozen_init_timesteps=-1, dpm_algorithm_type="null", dpm_apply_strategy="post",
              dpm_post_compress_ratio=0.4, dpm_solver_order=2, dpm_solver_type="midpoint",
              sample_strategy="progressive", output_dir="data/outputs", experiment_name="exp", reward_model="synthetic",
-             rollout_batch=0, train_microbatch=0)
+             rollout_batch=0, train_microbatch=0, skip_dead_backward=False)
     a.update(kw)
     return Namespace(**a)
 
@@ -270,13 +270,18 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
     for c0 in range(0, len(order), accum):
         chunk = order[c0:c0 + accum]
         pairs = [(i, t) for i in chunk for t in steps_of(i)]
+        # The gradients of a leftover chunk (G % accum samples) are never applied: the reference backpropagates them and
+        # the next train step's zero_grad() discards them (:360,605-609).  Default: do the same work.  With
+        # `args.skip_dead_backward` only their forward runs (their losses still enter the logged averages): every
+        # returned value and the weights are identical, the dead backward passes are not executed.
+        dead = len(chunk) < accum and getattr(args, "skip_dead_backward", False)
         if pairs:
             pairs.sort(key=lambda p: p[1])                     # step-major: one coefficient set per contiguous slice
             for m0 in range(0, len(pairs), mb or len(pairs)):
                 part = pairs[m0:m0 + (mb or len(pairs))]
                 _replay_backward(args, transformer, part, lat_steps, all_log_probs, adv, encoder_hidden_states,
                                  pooled_prompt_embeds, txt_ids, img_ids, guidance, timestep_value, sig_host, denom, log,
-                                 trace)
+                                 trace, need_grad=not dead)
         if len(chunk) == accum:                                # optimizer step every `accum` samples (:605-609)
             grad_norm = _fused_step(transformer, optimizer, max_grad_norm)
             lr_scheduler.step()
@@ -293,7 +298,7 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
 
 
 def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, ehs, pooled, txt_ids, img_ids, guidance,
-                     timestep_value, sig_host, denom, log, trace):
+                     timestep_value, sig_host, denom, log, trace, need_grad=True):
     """Forward + backward of a batch of (sample, step) pairs; accumulates parameter grads and the logging sums."""
     dev = lat_steps.device
     idx_s = torch.tensor([p[0] for p in pairs], device=dev)
@@ -303,7 +308,7 @@ def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, eh
     old_lp = all_log_probs[idx_s, idx_t].contiguous()
     a = adv[idx_s].contiguous()
     ts = _timestep_tensor([timestep_value[p[1]] for p in pairs], dev)
-    with torch.autocast("cuda", torch.bfloat16):
+    with torch.autocast("cuda", torch.bfloat16), torch.set_grad_enabled(need_grad):
         pred = transformer(hidden_states=x, encoder_hidden_states=ehs[idx_s].contiguous(), timestep=ts,
                            guidance=guidance, txt_ids=txt_ids, pooled_projections=pooled[idx_s].contiguous(),
                            img_ids=img_ids, joint_attention_kwargs=None, return_dict=False)[0]

@@ -140,6 +140,32 @@ def test_backward_vs_oracle_autograd(B, hg, wg, L):
     assert rel_err(m.store.view(g, k0), 2 * Pg[k0].grad) < 4e-2
 
 
+@pytest.mark.parametrize("growth", [0.0, 3.0, 40.0])
+def test_attention_deferred_rescale_paths(growth):
+    """The forward's online softmax raises its running maximum only when a row outgrows it by 2^6 (attention.hip,
+    DEFER): keys whose scores GROW along the sequence force, per 64-key tile, either the deferred path with P > 1
+    (growth 3: ~2^0.3 per tile) or the rescale branch over and over (growth 40), at a ragged length; a random-data check
+    alone never leaves the first-tile rescale.  Tolerances as test_attention_kernel_vs_torch."""
+    from mixgrpo_amd import ops
+    B, H, S = 1, 3, 1000
+    Sp = (S + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(2)
+    q = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    base = torch.randn(B, H, S, 128, device="cuda", generator=g)
+    ramp = torch.linspace(0, 1, S, device="cuda").view(1, 1, S, 1)
+    k = (base + growth * ramp * q.float().mean(dim=2, keepdim=True).sign()).bfloat16()   # scores drift upwards with the key index
+    v = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    vt = torch.cat([v.transpose(-1, -2), torch.zeros(B, H, 128, Sp - S, device="cuda", dtype=v.dtype)], -1).contiguous()
+    O = torch.empty(B, S, H * 128, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attn_fwd(q, k, vt, O, lse, B, H, S, Sp, H * 128, S * H * 128, 1 / math.sqrt(128))
+    s = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128)
+    ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, S, H * 128)
+    assert torch.isfinite(O.float()).all()
+    assert rel_err(O, ref) < 6e-3
+    assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+
+
 def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
     """The training forward keeps the attention output / LSE and the pre-gate outputs of to_out, ff.net.2 and proj_out so
     that the recompute pass skips attention and those GEMMs (flux_backward._Train.keep).  The kept values are the very

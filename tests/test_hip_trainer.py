@@ -93,3 +93,40 @@ def test_train_one_step_vs_oracle(tag, kw, rewards, weights, window):
         assert rp[1] == pytest.approx(ro[1], rel=2e-3, abs=1e-7)
     assert rp[5] == ro[5] or rp[5] == pytest.approx(ro[5], rel=1e-6)
     assert mp.a.item() == pytest.approx(mo.a.item(), rel=1e-4)
+
+
+def test_skip_dead_backward_changes_nothing_but_work():
+    """`args.skip_dead_backward`: the backward passes of the G % accum leftover samples (gradients the reference computes
+    and then discards, train_grpo_flux.py:360,605-609) are not executed; every returned value and the updated weights
+    must be identical to the default, reference-faithful run."""
+    from mixgrpo_amd import train_grpo_flux as TG
+    rewards = [0.3, 0.1, 0.8, 0.4, 0.6]
+    a = base_args(num_generations=5, gradient_accumulation_steps=2)
+    G, T = a.num_generations, a.sampling_steps
+    lh, lw = a.h // 8, a.w // 8
+    N = (lh // 2) * (lw // 2)
+    g = torch.Generator().manual_seed(5)
+    inj = {"x_T": torch.randn(1, 16, lh, lw, generator=g).bfloat16(),
+           "steps": [torch.randn(G, N, 64, generator=g).bfloat16() for _ in range(T)]}
+    batch = ((0.1 * torch.randn(1, 8, 32, generator=g)).bfloat16(), torch.randn(1, 16, generator=g).bfloat16(),
+             torch.zeros(1, 3), ["p"])
+
+    def reward(latents, captions):
+        n = latents.shape[0]
+        return [rewards[i] for i in range(n)], {"A": [rewards[i] for i in range(n)]}
+
+    outs = []
+    for skip in (False, True):
+        m = ElementwiseToy().cuda()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+        ap = copy.copy(a)
+        ap.injected_noise = inj
+        ap.skip_dead_backward = skip
+        calls = {"bwd": 0}
+        h = m.a.register_hook(lambda gr: calls.__setitem__("bwd", calls["bwd"] + 1))
+        res = TG.train_one_step(ap, torch.device("cuda"), m, None, reward, opt, _Sched(), iter([batch]), None, 1.0, [3, 4],
+                                0, {"A": 1.0})
+        h.remove()
+        outs.append((res, m.a.item(), calls["bwd"]))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert outs[1][2] < outs[0][2]                      # fewer backward passes really ran
