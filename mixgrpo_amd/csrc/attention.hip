@@ -11,8 +11,8 @@
 // tile).  S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with K as the A operand, so a lane holds one query column
 // and 16 of the 32 keys of a block: the softmax row statistics are lane-local plus ONE exchange with lane^32.
 // The S^T accumulator is converted in place to the B operand of O^T += Vt P^T (accumulator-as-operand, no LDS
-// round trip); Vt is read from LDS with the matching permuted key order.  LDS images are XOR-swizzled so the
-// ds_read_b128 (K) and ds_read_b64 (Vt) fragment reads are bank-conflict free.
+// round trip); Vt is stored in LDS in the matching permuted key order, so both the K and the Vt fragments are single,
+// bank-conflict-free ds_read_b128 (XOR-swizzled images).
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
@@ -41,8 +41,12 @@ struct AttnArgs {
 
 // K tile image: [64 keys][16 chunks of 16 B], chunk ^= key & 15
 __device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }
-// Vt tile image: [128 d][16 chunks of 8 B], chunk ^= (d >> 1) & 15
-__device__ __forceinline__ int v_off(int d, int chunk8) { return d * 128 + ((chunk8 ^ ((d >> 1) & 15)) << 3); }
+// Vt tile image: [128 d][8 slots of 16 B].  Slot (b, h) of a row holds, for the 16-key block b, the keys 4h+{0..3} and
+// 4h+8+{0..3}: exactly the 8 keys (in the S^T accumulator's order) that lane half h feeds to one P V MFMA, so the A
+// operand is ONE ds_read_b128.  (Two ds_read_b64 per operand get fused by hipcc into ds_read2st64_b64, which runs at
+// half the LDS rate and banks modulo 32: the 64-bank swizzle then conflicts 2-way -- SQ_LDS_BANK_CONFLICT was 39 % of
+// the LDS-active cycles and the LDS port, not the matrix pipe, paced the kernel.)  slot ^= (d >> 1) & 7.
+__device__ __forceinline__ int v_off(int d, int slot16) { return d * 128 + ((slot16 ^ ((d >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -108,8 +112,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
 #define STORE1(i_, SK, SV)                                                                          \
   if constexpr (NCH > i_) {                                                                         \
     *reinterpret_cast<uint4*>(kb_ptr + k_off(kc_key0 + KSTEP * i_, kc_chunk)) = SK;                 \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk)) = make_uint2(SV.x, SV.y); \
-    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, 2 * vc_chunk + 1)) = make_uint2(SV.z, SV.w); \
+    /* 16-byte chunk vc_chunk = keys 8c..8c+7 of the tile: 4-key groups g = 2c, 2c+1 of block b = c >> 1 */ \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, (vc_chunk >> 1) * 2) + (vc_chunk & 1) * 8) = make_uint2(SV.x, SV.y); \
+    *reinterpret_cast<uint2*>(vb_ptr + v_off(vc_d0 + DSTEP * i_, (vc_chunk >> 1) * 2 + 1) + (vc_chunk & 1) * 8) = make_uint2(SV.z, SV.w); \
   }
 #define STORE_KV(buf)                                                                               \
   do {                                                                                              \
@@ -215,15 +220,13 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
           const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
           pf = __builtin_bit_cast(s16x8, u);
         }
-        // keys (within the tile) kb*32 + 16*s2 + 4h + {0..3} and +8
-        const int c8 = (kb * 32 + 16 * s2 + 4 * h) >> 2;   // 8-byte chunk index (4 keys per chunk)
+        // keys (within the tile) kb*32 + 16*s2 + 4h + {0..3} and +8: slot (b = 2 kb + s2, h) of the Vt image
+        const int slot = (kb * 2 + s2) * 2 + h;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const int d = dt * 32 + r;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8));
-          const uint2 hi = *reinterpret_cast<const uint2*>(vs_ + v_off(d, c8 + 2));
-          const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, u), pf, o[dt], 0, 0, 0);
+          const s16x8 vfrag = *reinterpret_cast<const s16x8*>(vs_ + v_off(d, slot));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pf, o[dt], 0, 0, 0);
         }
       }
     if (t + 1 < ntiles) STORE_KV(cur ^ 1);

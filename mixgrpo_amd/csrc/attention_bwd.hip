@@ -27,10 +27,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 // row-major [rows][128] bf16 image, 16-byte chunk swizzle
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
-// transposed [128 d][64 cols] image (128-byte rows), 8-byte chunk swizzle
-__device__ __forceinline__ int t64_off(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
-// transposed [128 d][32 cols] image (64-byte rows), 8-byte chunk swizzle
-__device__ __forceinline__ int t32_off(int d, int c8) { return d * 64 + ((c8 ^ ((d >> 2) & 7)) << 3); }
+// Transposed images [128 d][64 or 32 columns] in 16-byte SLOTS: slot (b, h) of a row holds, for the 16-column block b,
+// the columns 4h+{0..3} and 4h+8+{0..3} -- the 8 columns (in the S / dS accumulator's order) that lane half h feeds to
+// one MFMA, so every transposed A operand is ONE conflict-free ds_read_b128.  (Two ds_read_b64 per operand are fused by
+// hipcc into ds_read2st64_b64: half the LDS rate, modulo-32 banking, 2-way conflicts; see attention.hip.)
+// 64 columns: 128-byte rows, 8 slots, slot ^= (d >> 1) & 7.   32 columns: 64-byte rows, 4 slots, slot ^= ((d >> 2) ^ (d >> 1)) & 3
+// (both checked exhaustively against the ds_read_b128 lane groups and the ds_write_b64 groups).
+__device__ __forceinline__ int t64_off(int d, int slot) { return d * 128 + ((slot ^ ((d >> 1) & 7)) << 4); }
+__device__ __forceinline__ int t32_off(int d, int slot) { return d * 64 + ((slot ^ (((d >> 2) ^ (d >> 1)) & 3)) << 4); }
 
 __device__ __forceinline__ void xcd_remap(int& bid, int nwg) {
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -115,11 +119,16 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   int krow = key0 + r;
   const bool key_valid = krow < g.S;
   if (krow >= g.S) krow = g.S - 1;
-  s16x8 kf[8], vf[8];
+  // K fragments stay in registers; the V fragments live in a wave-private LDS area ([ks][lane] 16-byte pieces, read
+  // back lane-linear): with both in registers the kernel needs ~290 VGPRs and hipcc spills 32 of them to scratch and
+  // reloads them INSIDE the q-tile loop, where each reload's vmcnt wait also drains the staging loads issued early.
+  s16x8 kf[8];
+  char* vfrag = smem + 2 * DKV_STAGE + wid * 8192 + lane * 16;
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     kf[ks] = *reinterpret_cast<const s16x8*>(g.K + (bhS + krow) * HD + ks * 16 + h * 8);
-    vf[ks] = *reinterpret_cast<const s16x8*>(g.V + (bhS + krow) * HD + ks * 16 + h * 8);
+    *reinterpret_cast<s16x8*>(vfrag + ks * 1024) =
+        *reinterpret_cast<const s16x8*>(g.V + (bhS + krow) * HD + ks * 16 + h * 8);
   }
   f32x16 dv[4], dk[4];   // dV^T, dK^T tiles: rows d = 32*dt + ..., column = key r
 #pragma unroll
@@ -155,10 +164,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
     char* base = smem + (buf) * DKV_STAGE;                                                            \
     *reinterpret_cast<uint4*>(base + rm_off(s_row, s_chunk)) = rq;                                    \
     *reinterpret_cast<uint4*>(base + 8192 + rm_off(s_row, s_chunk)) = rdo;                            \
-    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, 2 * s_c16)) = make_uint2(rqt.x, rqt.y);     \
-    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, 2 * s_c16 + 1)) = make_uint2(rqt.z, rqt.w); \
-    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, 2 * s_c16)) = make_uint2(rdot.x, rdot.y);   \
-    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, 2 * s_c16 + 1)) = make_uint2(rdot.z, rdot.w); \
+    /* 16-byte chunk s_c16 = queries 8c..8c+7: 4-query groups 2c (h = 0) and 2c+1 (h = 1) of block c >> 1 */ \
+    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, (s_c16 >> 1) * 2) + (s_c16 & 1) * 8) = make_uint2(rqt.x, rqt.y);     \
+    *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, (s_c16 >> 1) * 2 + 1) + (s_c16 & 1) * 8) = make_uint2(rqt.z, rqt.w); \
+    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, (s_c16 >> 1) * 2) + (s_c16 & 1) * 8) = make_uint2(rdot.x, rdot.y);   \
+    *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, (s_c16 >> 1) * 2 + 1) + (s_c16 & 1) * 8) = make_uint2(rdot.z, rdot.w); \
     if (tid < 64) reinterpret_cast<float*>(base + 32768)[tid] = rl;                                   \
   } while (0)
 
@@ -168,7 +178,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   // see attention.hip: make the pre-loop fragment loads provably complete so the loop's MFMAs are not fenced behind
   // the staging loads
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
   int cur = 0;
   auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
@@ -183,8 +193,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
     for (int ks = 0; ks < 8; ++ks) {
       const s16x8 qa = *reinterpret_cast<const s16x8*>(base + rm_off(r, ks * 2 + h));
       const s16x8 da = *reinterpret_cast<const s16x8*>(base + 8192 + rm_off(r, ks * 2 + h));
+      const s16x8 vfk = *reinterpret_cast<const s16x8*>(vfrag + ks * 1024);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vfk, dp, 0, 0, 0);
     }
     // P[q][key] and dS[q][key]; q = (i&3) + 8*(i>>2) + 4h (rows), key = this lane's column
     uint32_t pb[8], dsb[8];
@@ -203,18 +214,14 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const s16x8 pf = __builtin_bit_cast(s16x8, make_uint4(pb[4 * s2], pb[4 * s2 + 1], pb[4 * s2 + 2], pb[4 * s2 + 3]));
       const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
-      const int c8 = (16 * s2 + 4 * h) >> 2;
+      const int slot = s2 * 2 + h;   // queries 16 s2 + 4h + {0..3} and + 8
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int d = dt * 32 + r;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(base + 24576 + t32_off(d, c8));
-        const uint2 a1 = *reinterpret_cast<const uint2*>(base + 24576 + t32_off(d, c8 + 2));
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)), pf,
-                                                         dv[dt], 0, 0, 0);
-        const uint2 b0 = *reinterpret_cast<const uint2*>(base + 16384 + t32_off(d, c8));
-        const uint2 b1 = *reinterpret_cast<const uint2*>(base + 16384 + t32_off(d, c8 + 2));
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(b0.x, b0.y, b1.x, b1.y)), df,
-                                                         dk[dt], 0, 0, 0);
+        const s16x8 a = *reinterpret_cast<const s16x8*>(base + 24576 + t32_off(d, slot));
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[dt], 0, 0, 0);
+        const s16x8 bq = *reinterpret_cast<const s16x8*>(base + 16384 + t32_off(d, slot));
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, df, dk[dt], 0, 0, 0);
       }
     }
     if (t + 1 < nqt) DKV_STORE(cur ^ 1);
@@ -303,10 +310,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
     *reinterpret_cast<uint4*>(base + rm_off(kc_key0 + 32, kc_chunk)) = sk1;                         \
     *reinterpret_cast<uint4*>(base + 16384 + rm_off(kc_key0, kc_chunk)) = sv0;                      \
     *reinterpret_cast<uint4*>(base + 16384 + rm_off(kc_key0 + 32, kc_chunk)) = sv1;                 \
-    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, 2 * vc_chunk)) = make_uint2(st0.x, st0.y); \
-    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, 2 * vc_chunk + 1)) = make_uint2(st0.z, st0.w); \
-    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, 2 * vc_chunk)) = make_uint2(st1.x, st1.y); \
-    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, 2 * vc_chunk + 1)) = make_uint2(st1.z, st1.w); \
+    /* 16-byte chunk vc_chunk = keys 8c..8c+7: 4-key groups 2c (h = 0) and 2c+1 (h = 1) of block c >> 1 */ \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, (vc_chunk >> 1) * 2) + (vc_chunk & 1) * 8) = make_uint2(st0.x, st0.y); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0, (vc_chunk >> 1) * 2 + 1) + (vc_chunk & 1) * 8) = make_uint2(st0.z, st0.w); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, (vc_chunk >> 1) * 2) + (vc_chunk & 1) * 8) = make_uint2(st1.x, st1.y); \
+    *reinterpret_cast<uint2*>(base + 32768 + t64_off(vc_d0 + 64, (vc_chunk >> 1) * 2 + 1) + (vc_chunk & 1) * 8) = make_uint2(st1.z, st1.w); \
   } while (0)
 
   DQ_LOAD(0);
@@ -348,14 +356,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
-        const int c8 = (kb * 32 + 16 * s2 + 4 * h) >> 2;
+        const int slot = (kb * 2 + s2) * 2 + h;   // keys 32 kb + 16 s2 + 4h + {0..3} and + 8
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const int d = dt * 32 + r;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(base + 32768 + t64_off(d, c8));
-          const uint2 a1 = *reinterpret_cast<const uint2*>(base + 32768 + t64_off(d, c8 + 2));
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)),
-                                                           df, dq[dt], 0, 0, 0);
+          const s16x8 a = *reinterpret_cast<const s16x8*>(base + 32768 + t64_off(d, slot));
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df, dq[dt], 0, 0, 0);
         }
       }
     }
@@ -396,12 +402,12 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   g.scale = scale; g.scale_log2e = scale * 1.4426950408889634f;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE + 65536);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DQ_STAGE);
     attr = true;
   }
   const int nb = cdiv(S, 256) * H * B;
-  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE, st>>>(g);
+  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
   attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
