@@ -147,18 +147,34 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
     const char* ks_ = smem + cur * (K_TILE_BYTES + V_TILE_BYTES);
     const char* vs_ = ks_ + K_TILE_BYTES;
 
-    // ---- S^T blocks (32 keys x 32 queries) x 2
+    // ---- S^T blocks (32 keys x 32 queries) x 2.  All eight K fragments of a block are requested before its MFMA
+    // chain, and the second block's fragments re-fill each register as soon as its MFMA has issued: written as
+    // "read; mfma" pairs, hipcc funnels every fragment through ONE register quad and emits read -> lgkmcnt(0) -> MFMA
+    // sixteen times, exposing the LDS latency on every MFMA.
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    {
+      s16x8 kf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const s16x8*>(ks_ + k_off(r, ks * 2 + h));
+      __builtin_amdgcn_sched_barrier(0);           // (the scheduler otherwise sinks every read back to its MFMA)
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const s16x8 kf = *reinterpret_cast<const s16x8*>(ks_ + k_off(kb * 32 + r, ks * 2 + h));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[0], 0, 0, 0);
+        kf[ks] = *reinterpret_cast<const s16x8*>(ks_ + k_off(32 + r, ks * 2 + h));
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[1], 0, 0, 0);
     }
+    // first Vt fragments of the P V product: requested here so that they return underneath the softmax
+    s16x8 vfr[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vfr[0][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, h));
+    __builtin_amdgcn_sched_barrier(0);
     // ---- mask keys beyond S (only the ragged last tile is compiled with MASK)
     if (MASK) {
       const int key_base = t * KB;
@@ -210,25 +226,24 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
       }
     l_run = l_run * alpha + psum;
 
-    // ---- O^T += Vt P^T : A = Vt[d = 32*dt + r][keys in the accumulator's permuted order]
+    // ---- O^T += Vt P^T : A = Vt[d = 32*dt + r][slot (b = 2 kb + s2, h)]: the 8 keys of lane half h in the S^T
+    // accumulator's order; the four fragments of step idx + 1 are requested before the MFMAs of step idx
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int idx = 0; idx < 4; ++idx) {
+      const int kb = idx >> 1, s2 = idx & 1;
+      const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
+      const s16x8 pf = __builtin_bit_cast(s16x8, u);
+      if (idx + 1 < 4) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        s16x8 pf;
-        {
-          const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
-          pf = __builtin_bit_cast(s16x8, u);
-        }
-        // keys (within the tile) kb*32 + 16*s2 + 4h + {0..3} and +8: slot (b = 2 kb + s2, h) of the Vt image
-        const int slot = (kb * 2 + s2) * 2 + h;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 32 + r;
-          const s16x8 vfrag = *reinterpret_cast<const s16x8*>(vs_ + v_off(d, slot));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pf, o[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 4; ++dt)
+          vfr[(idx + 1) & 1][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, (idx + 1) * 2 + h));
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[idx & 1][dt], pf, o[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (t + 1 < ntiles) STORE_KV(cur ^ 1);
     __syncthreads();
     cur ^= 1;
