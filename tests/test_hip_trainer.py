@@ -43,6 +43,13 @@ CASES = [
     ("flash_post", dict(sampling_steps=12, dpm_algorithm_type="dpmsolver++", dpm_post_compress_ratio=0.4),
      {"A": [0.4, 0.2, 0.3, 0.1]}, {"A": 1.0}, [0, 1]),
     ("microbatched", dict(rollout_batch=2, train_microbatch=3), {"A": [0.1, 0.2, 0.3, 0.4]}, {"A": 1.0}, [2, 3]),
+    # BASELINE.json configs[2] / configs[4] shapes of the schedule (bf16 attention): three reward heads with weights 1.0
+    # on a group of 12, and a 50-step sampler with a 4-step window in the middle of the trajectory on a group of 16
+    ("three_heads_g12", dict(num_generations=12, gradient_accumulation_steps=3),
+     {"HPS": [0.1 * i for i in range(12)], "IR": [((7 * i) % 12) / 12 for i in range(12)],
+      "Pick": [((5 * i + 3) % 12) / 6 for i in range(12)]}, {"HPS": 1.0, "IR": 1.0, "Pick": 1.0}, [0, 1, 2, 3]),
+    ("sliding50_g16", dict(sampling_steps=50, num_generations=16, gradient_accumulation_steps=3),
+     {"A": [((11 * i + 2) % 16) / 16 for i in range(16)]}, {"A": 1.0}, [10, 11, 12, 13]),
 ]
 
 
