@@ -71,11 +71,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()      # (== local_rank on a full node; lets a 1-GPU box rehearse N ranks over gloo)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        backend = os.environ.get("MGX_DIST_BACKEND", "nccl")                            # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        # build the RCCL communicator (rings over xGMI) now: with --warmup 0 it would otherwise be created inside the
+        # timed step by the first reward all-gather
+        _w = torch.ones(1 << 20, device=dev)
+        dist.all_reduce(_w)
+        dist.all_gather([torch.empty(4, device=dev) for _ in range(world)], torch.ones(4, device=dev))
+        torch.cuda.synchronize()
+        del _w
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from mixgrpo_amd import ops
@@ -150,10 +162,14 @@ def main():
     flop_img = (T + 3 * W - 2.0 * W * dead / G) * f_fwd
 
     roofline = None
-    if not a.no_roofline and rank == 0:
-        ops.GEMM_PROFILE = []
+    if not a.no_roofline:
+        # one extra, untimed train step with HIP events around every GEMM launch.  EVERY rank runs it (a train step is
+        # full of collectives: rank 0 alone would deadlock the job); only rank 0 records and reports.
+        if rank == 0:
+            ops.GEMM_PROFILE = []
         one_step()
         torch.cuda.synchronize()
+    if not a.no_roofline and rank == 0:
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ops.GEMM_PROFILE)
         tot_fl = sum(f for _, _, f, _ in ops.GEMM_PROFILE)
         n_launch = len(ops.GEMM_PROFILE)
@@ -192,13 +208,11 @@ def main():
                     "avg_launch_ms": round(tot_ms / max(1, n_launch), 4),
                     "gemm_share_of_step": round(tot_ms * 1e-3 / (dt / a.steps), 3),
                     "train_step_frac_of_peak": round(flop_img * value / world / (PEAK_BF16_TFLOPS * 1e12), 4)}
-    elif world > 1 and not a.no_roofline:
-        pass
     if world > 1:
         dist.barrier()
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0:
+    if not a.no_cpu_baseline and rank == 0 and world == 1:       # a reported baseline, N = 1 only
         cpu = cpu_baseline(flop_img)
 
     if rank == 0:
