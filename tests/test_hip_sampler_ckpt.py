@@ -97,3 +97,33 @@ def test_checkpoint_and_resume_roundtrip(tmp_path):
         s_.step()
         w.update_iteration()
     assert torch.equal(m2.store.w32, m.store.w32) and st2.get_current_timesteps() == st.get_current_timesteps()
+
+
+def test_reward_adapter_decode_contract():
+    """reward_adapter: the latents handed to `vae.decode` are unpack(packed) / 0.3611 + 0.1159 in [n, 16, h/8, w/8] layout
+    (reference train_grpo_flux.py:284-288), and the per-model / weighted rewards follow the trainer's call-site contract."""
+    from mixgrpo_amd.latents import pack_latents
+    from mixgrpo_amd.reward_adapter import make_reward_function
+    n, h, w = 3, 64, 96
+    z = torch.randn(n, 16, h // 8, w // 8, generator=torch.Generator().manual_seed(0)).cuda()
+    packed = pack_latents(z, n, 16, h // 8, w // 8)
+    seen = {}
+
+    class FakeVAE:
+        def enable_tiling(self):
+            seen["tiling"] = True
+
+        def decode(self, lat, return_dict=False):
+            seen["lat"] = lat.clone()
+            return (lat.float().mean(dim=(1, 2, 3)),)          # one "image" scalar per sample
+
+    models = {"HPSClipRewardModel": lambda imgs, prompts: [float(i) for i in imgs],
+              "PickScoreRewardModel": lambda imgs, prompts: [float(len(p)) for p in prompts]}
+    weights = {"HPSClipRewardModel": 1.0, "PickScoreRewardModel": 0.5}
+    fn = make_reward_function(FakeVAE(), models, weights, h, w)
+    total, per = fn(packed, ["a", "bb", "ccc"])
+    assert seen["tiling"] and seen["lat"].shape == (n, 16, h // 8, w // 8)
+    assert torch.allclose(seen["lat"].float(), z / 0.3611 + 0.1159, rtol=1e-6, atol=1e-6)
+    assert per["PickScoreRewardModel"] == [1.0, 2.0, 3.0] and len(per["HPSClipRewardModel"]) == n
+    for t, a, b in zip(total, per["HPSClipRewardModel"], per["PickScoreRewardModel"]):
+        assert abs(t - (a + 0.5 * b)) < 1e-6
