@@ -57,7 +57,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flux1dev_1024_T25_W4_G8", choices=list(WORKLOADS))
-    ap.add_argument("--train-microbatch", type=int, default=6)
+    ap.add_argument("--train-microbatch", type=int, default=7,
+                    help="replayed (sample, step) pairs per forward/backward; 7 -> micro-batches of 7+5 (and 7+1 for the leftover "
+                         "chunk), whose GEMM tile counts sit closer to multiples of the 256 CUs than 6+6")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-dead-backward", action="store_true",

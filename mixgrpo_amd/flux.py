@@ -179,7 +179,9 @@ def rope_tables(ids, axes_dims, theta=10000.0):
 
 
 class _Work:
-    """Activation workspace for one (B, L, N) problem size, reused across calls."""
+    """Activation workspace for one (L, N) problem shape at a batch CAPACITY B; calls with a smaller batch use leading
+    slices of it (`view`), so the rollout (B = G), the shared first step (B = 1) and the replay micro-batches share one
+    allocation instead of one per batch size."""
 
     def __init__(self, cfg, B, L, N, device):
         d, H, hd = cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
@@ -199,6 +201,30 @@ class _Work:
         self.in16 = e(B * N, cfg.in_channels)
         self.out = e(B, N, cfg.patch_size * cfg.patch_size * cfg.in_channels)
         self.lse = e(B, H, S, dtype=F32)
+        self.train = None                         # flux_backward._Train, at its own batch capacity
+
+    def view(self, B):
+        return self if B == self.B else _WorkView(self, B)
+
+
+class _WorkView:
+    """The first B batches of a `_Work` (all buffers are batch-major and contiguous, so these are plain prefixes)."""
+
+    def __init__(self, base, B):
+        assert B <= base.B
+        self.base, self.B, self.L, self.N, self.S, self.Sp = base, B, base.L, base.N, base.S, base.Sp
+        M = B * base.S
+        self.X, self.Q, self.K, self.Vt, self.O, self.cat = (t[:B] for t in (base.X, base.Q, base.K, base.Vt, base.O, base.cat))
+        self.nrm, self.qkv, self.hid = base.nrm[:M], base.qkv[:M], base.hid[:M]
+        self.in16, self.out, self.lse = base.in16[:B * base.N], base.out[:B], base.lse[:B]
+
+    @property
+    def train(self):
+        return self.base.train
+
+    @train.setter
+    def train(self, v):
+        self.base.train = v
 
 
 class FluxTransformer2DModel(torch.nn.Module):
@@ -214,7 +240,7 @@ class FluxTransformer2DModel(torch.nn.Module):
         self.store = ParamStore(self.cfg, dev)
         # one flat fp32 parameter (what optimizers / clip_grad_norm_ see); named views via state_dict()
         self.flat_param = torch.nn.Parameter(self.store.w32, requires_grad=True)
-        self._work: Dict[Tuple[int, int, int], _Work] = {}
+        self._work: Dict[Tuple[int, int], _Work] = {}
         self._rope_cache = {}
         self.recompute = True
 
@@ -256,14 +282,19 @@ class FluxTransformer2DModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B, L, N):
-        key = (B, L, N)
-        w = self._work.get(key)
-        if w is None:
-            if len(self._work) >= 2:   # keep at most two problem sizes resident (rollout + replay)
+        """Workspace view for batch B of the (L, N) shape; the base grows to the largest batch seen."""
+        key = (L, N)
+        base = self._work.get(key)
+        if base is None or base.B < B:
+            if base is not None:
+                self._work.pop(key)
+                del base
+            elif len(self._work) >= 2:   # keep at most two sequence shapes resident
                 self._work.pop(next(iter(self._work)))
-            w = _Work(self.cfg, B, L, N, self.store.device)
-            self._work[key] = w
-        return w
+            torch.cuda.empty_cache()     # hand the outgrown buffers back before allocating the larger ones
+            base = _Work(self.cfg, B, L, N, self.store.device)
+            self._work[key] = base
+        return base.view(B)
 
     def _rope(self, txt_ids, img_ids):
         key = (id(txt_ids), txt_ids._version, tuple(txt_ids.shape), id(img_ids), img_ids._version, tuple(img_ids.shape))

@@ -26,11 +26,13 @@ def _pad64(n):
 
 
 class _Train:
-    """Extra buffers for one (B, L, N) training problem."""
+    """Extra buffers of the training pass for one (L, N) shape at a batch CAPACITY B (smaller micro-batches use
+    leading slices: `view`)."""
 
     def __init__(self, cfg, w, device):
         d, H, hd = cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
         B, S, Sp = w.B, w.S, w.Sp
+        self.B, self.S = B, S
         M = B * S
         e = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=device)
         z = lambda *shape, dtype=BF16: torch.zeros(*shape, dtype=dtype, device=device)
@@ -65,6 +67,41 @@ class _Train:
         self.Wt = e(7 * d * max(d, 64) + 5 * d * d)
         self.ones = torch.ones(1, 5 * d, dtype=BF16, device=device)
 
+    def view(self, B):
+        return self if B == self.B else _TrainView(self, B)
+
+
+class _TrainView:
+    """The first B batches of a `_Train` (batch-major contiguous buffers: plain prefixes; flat operand buffers shared)."""
+
+    def __init__(self, base, B):
+        assert B <= base.B
+        M = B * base.S
+        self.B, self.S = B, base.S
+        self.block_in = [base.block_in[i, :B] for i in range(base.block_in.shape[0])]
+        self.x_final = base.x_final[:B]
+        rows = ("nrm1", "nrm2", "y_attn", "y_ff", "hid_pre")
+        self.save = {k: (v[:M] if k in rows else v[:B]) for k, v in base.save.items()}
+        self.keep = None
+        if base.keep is not None:
+            self.keep = [{k: (v[:M] if k in ("y_attn", "y_ff") else v[:B]) for k, v in kb.items()} for kb in base.keep]
+        self.dX, self.dO, self.dQ, self.dK, self.dV, self.dOt, self.delta = (
+            t[:B] for t in (base.dX, base.dO, base.dQ, base.dK, base.dV, base.dOt, base.delta))
+        self.dy, self.dbig, self.dnrm = base.dy[:M], base.dbig[:M], base.dnrm[:M]
+        self.dCt, self.At, self.Wt, self.ones = base.dCt, base.At, base.Wt, base.ones
+
+
+def _train_buffers(cfg, w, device):
+    """`_Train` view for the workspace view `w`; the base grows to the largest training batch seen."""
+    base = w.train
+    if base is None or base.B < w.B:
+        w.train = None
+        del base
+        torch.cuda.empty_cache()
+        base = _Train(cfg, w, device)
+        w.train = base
+    return base.view(w.B)
+
 
 class FluxFunction(torch.autograd.Function):
     @staticmethod
@@ -74,10 +111,7 @@ class FluxFunction(torch.autograd.Function):
         B, N, _ = hidden_states.shape
         L = encoder_hidden_states.shape[1]
         w = model._workspace(B, L, N)
-        tr = getattr(w, "train", None)
-        if tr is None:
-            tr = _Train(cfg, w, model.store.device)
-            w.train = tr
+        tr = _train_buffers(cfg, w, model.store.device)
         ehs = model._embed(w, hidden_states, encoder_hidden_states)
         keep = {}
         temb, st = model._temb(B, timestep.to(model.store.device), guidance, pooled_projections, keep=keep)
