@@ -17,7 +17,7 @@ def bench(M, N, K, epi=0, iters=8):
     for _ in range(iters): ops.gemm(Rows.of(A), W, None if epi == 3 else b, Rows.of(C), N, K, epi, **kw)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print(f"skew={os.environ.get('MGX_GEMM_SKEW','0'):>3} M{M} N{N} K{K} epi{epi}: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)
+    print(f"tag={os.environ.get('MGX_BENCH_TAG','0'):>3} M{M} N{N} K{K} epi{epi}: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)
 shapes = [(36864,9216,3072,0),(36864,12288,3072,1),(36864,3072,15360,2),(32768,3072,3072,2),(32768,3072,12288,2),
           (27648,9216,3072,0),(27648,12288,3072,1),(27648,3072,15360,2),(27648,3072,21504,0),(27648,12288,3072,4),
           (21504,3072,27648,3),(4096,9216,3072,0),(4096,12288,3072,1)]
