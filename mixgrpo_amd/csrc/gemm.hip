@@ -1,7 +1,9 @@
 // bf16 MFMA GEMM for the MMDiT linears (gfx950):  C[M,N] = epi( A[M,K] @ W[N,K]^T + bias )
 //
 // Both operands are K-contiguous ("NT"): activations [tokens, features] and torch Linear weights [out, in].
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16
+// Two kernels: `gemm_persist_kernel` (256x256x64 tiles, persistent, LDS-DMA staging: every problem with >= 192 such tiles,
+// i.e. all the FLOPs that matter; described at its definition) and `gemm_kernel` for the small problems:
+// tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16
 // accumulators.  Operands are staged global -> registers -> LDS (issue-early / write-late, one barrier per
 // K-tile, two LDS buffers); the LDS image is [row][64 k] with an XOR swizzle on the 16-byte chunk index
 // (chunk ^ ((row>>1)&7)) which makes every ds_read_b128 fragment read and every ds_write_b128 conflict-free.
@@ -71,89 +73,12 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Shared epilogue of the one-tile-per-workgroup kernels.  `BIGT`: 256x256 tile (wave sub-tile 128x64, MT = 8) whose
-// bf16 results may be staged through the (now idle) LDS and written row-wise.
-template <int EPI, bool BIG, int MT, int NTL>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NTL][MT], char* smem, int wid, int lane,
-                                              long m0, long n0, int wm, int wn) {
+// Epilogue of the 128x128 kernel: lane holds, for m-tile j and n-tile i, 4 consecutive features of one token.
+template <int EPI, int MT, int NTL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NTL][MT], int lane, long m0, long n0, int wm,
+                                              int wn) {
   const int fr = lane & 15, fq = lane >> 4;
-  // ---- epilogue A (256x256 tile, bf16 output): stage the wave's 128x64 sub-tile through LDS and finish it row-wise
-  // with 16-byte loads/stores (one full 128-byte line per 8 lanes): the 8-byte row-per-lane stores of epilogue B are
-  // store-ISSUE bound (17 us per tile = 18 % of a K=3072 GEMM); this form halves the store instructions and moves
-  // the gate / residual / aux traffic to 16-byte accesses too.
-  if (BIG && EPI != EPI_F32_ACC && g.rowwise_ok) {
-    char* reg = smem + wid * 16384;    // [128 rows][64 cols] bf16, 16-byte chunk index XOR (row & 7)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int row = j * 16 + fr;
-#pragma unroll
-      for (int i = 0; i < NTL; ++i) {
-        const long n = n0 + wn * 64 + i * 16 + fq * 4;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (g.bias && n < g.N) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-        }
-        uint2 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        const int c16 = i * 2 + (fq >> 1);
-        *reinterpret_cast<uint2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
-      }
-    }
-    // same-wave LDS ops complete in order; no block barrier needed (each wave owns its region)
-    const int rl = lane >> 3, c16 = lane & 7;
-    const long n = n0 + wn * 64 + c16 * 8;
-    long m = m0 + wm * 128 + rl;
-    long bidx = (uint32_t)m / (uint32_t)g.c.rpb;
-    long rin = m - bidx * g.c.rpb;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + rl;
-      if (m < g.M && n < g.N) {
-        const uint4 u = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
-        float v[8];
-        v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
-        v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
-        bf16_raw* cp = reinterpret_cast<bf16_raw*>(g.C) + bidx * g.c.bstride + rin * g.c.ld + n;
-        if (EPI == EPI_BIAS_GELU) {
-          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
-        } else if (EPI == EPI_BIAS_GATE_RES) {
-          if (g.aux) *reinterpret_cast<uint4*>(g.aux + m * g.ldaux + n) = u;
-          const uint4 gg = *reinterpret_cast<const uint4*>(g.gate + bidx * g.gate_ld + n);
-          const uint4 rr = *reinterpret_cast<const uint4*>(cp);
-          const uint32_t gw[4] = {gg.x, gg.y, gg.z, gg.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[2 * r] = bf2f(rw[r] & 0xffff) + rbf(bf2f(gw[r] & 0xffff) * v[2 * r]);
-            v[2 * r + 1] = bf2f(rw[r] >> 16) + rbf(bf2f(gw[r] >> 16) * v[2 * r + 1]);
-          }
-        } else if (EPI == EPI_BIAS_MULAUX) {
-          const uint4 pp = *reinterpret_cast<const uint4*>(g.aux + m * g.ldaux + n);
-          const uint32_t pw[4] = {pp.x, pp.y, pp.z, pp.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[2 * r] *= gelu_tanh_grad_f(bf2f(pw[r] & 0xffff));
-            v[2 * r + 1] *= gelu_tanh_grad_f(bf2f(pw[r] >> 16));
-          }
-        }
-        uint4 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        *reinterpret_cast<uint4*>(cp) = o;
-      }
-      m += 8;
-      rin += 8;
-      while (rin >= g.c.rpb) { rin -= g.c.rpb; ++bidx; }
-    }
-    return;
-  }
-
-  // ---- epilogue B: lane holds, for m-tile j and n-tile i: token m = m0+wm*64+j*16+fr, features n..n+3
+  // token m = m0 + wm*64 + j*16 + fr, features n .. n+3
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const long m = m0 + wm * (MT * 16) + j * 16 + fr;
@@ -218,22 +143,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NT
   }
 }
 
-// BIG = false: 128x128 tile, 256 threads (2x2 waves of 64x64).  BIG = true: 256x256 tile, 512 threads (2x4 waves of
-// 128(M) x 64(N)): half the LDS write traffic and 25 % less LDS read traffic per MFMA -- the LDS port, not the MFMA
-// pipe, is what limits the small tile (ds_write_b128 runs at ~79 B/clk/CU).
-// GLDS = true stages both operands with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write issue):
-// the LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE address.
-template <int EPI, bool BIG, bool GLDS>
-__global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
-  constexpr int TM = BIG ? 256 : 128, TN = BIG ? 256 : 128;       // block tile
-  constexpr int NTHR = BIG ? 512 : 256;
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
+  constexpr int TM = 128, TN = 128;                               // block tile
+  constexpr int NTHR = 256;
   constexpr int RS = NTHR / 8;                                    // rows covered by one pass of the loader
   constexpr int TB = TM * 128;                                    // bytes of one operand tile (64 k x 2 B per row)
   constexpr int STAGE = 2 * TB;
-  constexpr int MT = BIG ? 8 : 4, NTL = 4;                        // 16x16 tiles per wave along M / N
+  constexpr int MT = 4, NTL = 4;                                  // 16x16 tiles per wave along M / N
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = BIG ? (wid >> 2) : (wid >> 1), wn = BIG ? (wid & 3) : (wid & 1);
+  const int wm = wid >> 1, wn = wid & 1;
 
   // XCD-aware tile order: consecutive logical tiles (which share A/W panels) go to the same XCD
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -256,7 +176,7 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
   // ---- loader: thread owns 16-byte chunks (row = lrow + RS*i, kc = lkc), i = 0..3; RS*i leaves bits 1..3 of the row
   // alone, so the swizzle term is the same for all four and one LDS offset (+ RS*128*i) serves them
   const int lrow = tid >> 3, lkc = tid & 7;
-  const int src_kc = GLDS ? swz(lrow, lkc) : lkc;   // GLDS: linear LDS slot lkc of a row holds logical chunk lkc ^ f(row)
+  const int src_kc = lkc;
   auto a_ptr = [&](int i) {
     long m = m0 + lrow + RS * i;
     if (m >= g.M) m = g.M - 1;
@@ -270,19 +190,6 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
   const bf16_raw* ap0 = a_ptr(0); const bf16_raw* ap1 = a_ptr(1); const bf16_raw* ap2 = a_ptr(2); const bf16_raw* ap3 = a_ptr(3);
   const bf16_raw* wp0 = w_ptr(0); const bf16_raw* wp1 = w_ptr(1); const bf16_raw* wp2 = w_ptr(2); const bf16_raw* wp3 = w_ptr(3);
   const int lds0 = lrow * 128 + swz(lrow, lkc) * 16;
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) bf16_raw gbl_bf16;
-#define GLDS_ONE(gp, ko, off)                                                                                      \
-  __builtin_amdgcn_global_load_lds((gbl_bf16*)((gp) + (ko)), (lds_char*)(smem + (off)), 16, 0, 0)
-#define GLDS_TILE(kt, buf)                                                                                         \
-  do {                                                                                                             \
-    const long ko = (long)(kt) * BK;                                                                               \
-    const int wb_ = (buf) * STAGE + wid * 1024;   /* wave-uniform LDS base; the DMA adds lane*16 */                \
-    GLDS_ONE(ap0, ko, wb_); GLDS_ONE(ap1, ko, wb_ + RS * 128); GLDS_ONE(ap2, ko, wb_ + 2 * RS * 128);              \
-    GLDS_ONE(ap3, ko, wb_ + 3 * RS * 128);                                                                         \
-    GLDS_ONE(wp0, ko, wb_ + TB); GLDS_ONE(wp1, ko, wb_ + TB + RS * 128); GLDS_ONE(wp2, ko, wb_ + TB + 2 * RS * 128); \
-    GLDS_ONE(wp3, ko, wb_ + TB + 3 * RS * 128);                                                                    \
-  } while (0)
   uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
 #define LOAD_TILE(kt)                                                            \
   do {                                                                           \
@@ -317,23 +224,12 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nkt = g.K / BK;
-  if (GLDS) {
-    GLDS_TILE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    LOAD_TILE(0);
-    STORE_TILE(0);
-  }
+  LOAD_TILE(0);
+  STORE_TILE(0);
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (GLDS) {
-      // unconditional (the last iteration re-fetches the last tile into the idle buffer): keeps the K-loop body one
-      // scheduling region so the ds_read / MFMA interleave below can be pinned
-      GLDS_TILE(kt + 1 < nkt ? kt + 1 : kt, cur ^ 1);
-    } else if (kt + 1 < nkt) {
-      LOAD_TILE(kt + 1);
-    }
+    if (kt + 1 < nkt) LOAD_TILE(kt + 1);
     const char* sa = smem + cur * STAGE;
     const char* sw = sa + TB;
     // all fragments of the K-tile are requested up front (both 32-deep k-steps): the second k-step's ds_reads
@@ -360,31 +256,14 @@ __global__ void __launch_bounds__(BIG ? 512 : 256, 2) gemm_kernel(GemmArgs g) {
         for (int i = 0; i < NTL; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
     }
-    if (GLDS && BIG) {
-      // software pipeline: the fragment reads of MFMA group g+1 are issued before the MFMAs of group g
-      // (group = 8 MFMAs = two 16-row A fragments x the four W fragments); masks: 0x100 DS_READ, 0x8 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int grp = 0; grp < 8; ++grp) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-        if (grp == 2) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        else if (grp < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-    }
-    if (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (kt + 1 < nkt) {
-      STORE_TILE(cur ^ 1);
-    }
+    if (kt + 1 < nkt) STORE_TILE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 #undef LOAD_TILE
 #undef STORE_TILE
-#undef GLDS_TILE
-#undef GLDS_ONE
 
-  gemm_epilogue<EPI, BIG, MT, NTL>(g, acc, smem, wid, lane, m0, n0, wm, wn);
+  gemm_epilogue<EPI, MT, NTL>(g, acc, lane, m0, n0, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------ transpose
@@ -929,22 +808,19 @@ int launch(const GemmArgs& g, hipStream_t st) {
   const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= 192 && (g.N % 256 == 0 || g.N >= 2048);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 4;   // 0: 128^2, 1: 256^2 reg, 2: 256^2 LDS-DMA, 4: persistent
+  // MGX_GEMM_MODE=0 forces the 128x128 kernel everywhere (A/B and debugging)
+  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 4;
   if (big && mode == 4 && g.span32) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
     gemm_persist_kernel<EPI><<<grid, 512, 131072, st>>>(g);
-  } else if (mode == 3) gemm_kernel<EPI, false, true><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
-  else if (big && mode == 2) gemm_kernel<EPI, true, true><<<(int)tiles_big, 512, 131072, st>>>(g);
-  else if (big && mode == 1) gemm_kernel<EPI, true, false><<<(int)tiles_big, 512, 131072, st>>>(g);
-  else gemm_kernel<EPI, false, false><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+  } else {
+    gemm_kernel<EPI><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+  }
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
