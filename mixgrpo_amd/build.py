@@ -17,7 +17,7 @@ LIB = os.path.join(CSRC, "libmixgrpo_hip.so")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-variable", "-Wno-unused-result", "-Wno-unused-value"]
+          "-Wno-unused-variable", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("MGX_BUILD_EXTRA", "").split()
 # files whose results must be bit-identical to separately-rounded eager fp32 ops: no FMA contraction
 # (norm.hip: the reference's RoPE / RMSNorm / LayerNorm are separately rounded eager fp32 ops too, and without the flag
 # the two template instances of qk_norm_rope_fwd contract `y0*c0 - y1*s0` differently: the training forward and the

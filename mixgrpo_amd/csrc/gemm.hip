@@ -774,8 +774,16 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       MMA_GROUP(1, 2);
       MMA_GROUP(1, 3);
       PIN();
+#if defined(MGX_TIMING_ONLY_NO_KTILE_SYNC)  /* diagnostic builds (wrong results): what the per-K-tile rendezvous costs */
+#elif defined(MGX_TIMING_ONLY_NO_VMCNT)
+      __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0) only */
+      __builtin_amdgcn_s_barrier();
+#elif defined(MGX_TIMING_ONLY_NO_BARRIER)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#endif
       cur ^= 1;
     }
     // the epilogue touches no LDS: the next tile's K-loop (whose first K-tile is already resident) follows directly.
