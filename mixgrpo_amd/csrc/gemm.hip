@@ -985,8 +985,16 @@ __global__ void __launch_bounds__(512, 2) gemm_persist3_kernel(GemmArgs g) {
       PIN();
       // everything but the four A pieces issued in this iteration has landed: the next K-tile's W (this iteration) and A
       // (previous iteration) are complete; all fragment reads of this K-tile have returned (lgkmcnt(0))
+#if defined(MGX_TIMING_ONLY_NO_KTILE_SYNC)  /* diagnostic builds (wrong results) */
+#elif defined(MGX_TIMING_ONLY_NO_VMCNT)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+#elif defined(MGX_TIMING_ONLY_NO_BARRIER)
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#endif
       aslot = aslot == 2 ? 0 : aslot + 1;
       wslot ^= 1;
     }
