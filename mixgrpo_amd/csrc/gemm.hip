@@ -614,208 +614,13 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
   }
 }
 
+// Staging: all 160 KiB of LDS as THREE 32 KiB stages for A and TWO for W.  The A pieces of K-tile k+2 and the W pieces of
+// K-tile k+1 are issued in iteration k, W first; the end-of-iteration wait is a counted `vmcnt(4)` that leaves the four A
+// pieces (the youngest) in flight, so the activation operand -- streamed from HBM -- gets two K-tiles of lead and only the
+// weight operand (L2 / Infinity-Cache resident) has to land within one.  Raw s_barrier: __syncthreads() would drain the DMA
+// queue.  (With two 64 KiB stages and vmcnt(0) the per-K-tile rendezvous cost 16-20 %; see DESIGN.md.)  Needs K >= 128.
 template <int EPI>
 __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
-  constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, STAGE = 2 * TB, MT = 8, NTL = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
-  const int nwg = tiles_m * tiles_n;
-  const int nkt = g.K / BK;
-  // tile list of this workgroup: the XCD (blockIdx & 7) owns a contiguous range of the banded tile order and its
-  // workgroups take every (gridDim/8)-th tile of it
-  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
-  const int q = nwg >> 3, rem = nwg & 7;
-  const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  const int xend = xbeg + (xcd < rem ? q + 1 : q);
-  int t_lin = xbeg + lane_in_xcd;
-  if (t_lin >= xend) return;
-
-  const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar: LDS-DMA bases stay in SGPRs / M0
-  const int lrow = tid >> 3, lkc = tid & 7;
-  const int src_kc = swz(lrow, lkc);
-  const int wrow = wperm(lrow);                    // W row (inside its 64-row group) that lands in LDS row lrow
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) char gbl_char;
-  // per-lane DMA sources as 32-bit BYTE offsets from the (uniform) operand bases: the host checks both operands
-  // span < 4 GiB.  Half the registers of 64-bit pointers, and the uniform K offset folds into the scalar base.
-  uint32_t ao[4], wo[4];
-  long m0, n0;
-#define TILE_COORDS(tl, M0, N0)                                            \
-  do {                                                                     \
-    const int band = 8, per_band = band * tiles_n;                         \
-    const int b0 = (tl) / per_band;                                        \
-    const int rows_in_band = min(band, tiles_m - b0 * band);               \
-    const int in_band = (tl) - b0 * per_band;                              \
-    M0 = (long)(b0 * band + in_band % rows_in_band) * TM;                  \
-    N0 = (long)(in_band / rows_in_band) * TN;                              \
-  } while (0)
-#define TILE_OFFS(M0, N0, AO, WO)                                                          \
-  do {                                                                                     \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
-      long mm = M0 + lrow + k_ * RS;                                                       \
-      if (mm >= g.M) mm = g.M - 1;                                                         \
-      AO[k_] = (uint32_t)((row_off(g.a, mm) + src_kc * 8) * 2);                            \
-      long nn = N0 + k_ * 64 + wrow;                                                       \
-      if (nn >= g.N) nn = g.N - 1;                                                         \
-      WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
-    }                                                                                      \
-  } while (0)
-#define PGLDS_ONE(base, off, off_lds) \
-  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
-#define PGLDS_TILE(AO, WO, kt, buf)                                                                           \
-  do {                                                                                                        \
-    const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)(kt) * (BK * 2);                             \
-    const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)(kt) * (BK * 2);                             \
-    const int lb_ = (buf) * STAGE + wu * 1024;                                                                \
-    PGLDS_ONE(ab_, AO[0], lb_); PGLDS_ONE(ab_, AO[1], lb_ + RS * 128); PGLDS_ONE(ab_, AO[2], lb_ + 2 * RS * 128); \
-    PGLDS_ONE(ab_, AO[3], lb_ + 3 * RS * 128);                                                                \
-    PGLDS_ONE(wb_, WO[0], lb_ + TB); PGLDS_ONE(wb_, WO[1], lb_ + TB + RS * 128);                              \
-    PGLDS_ONE(wb_, WO[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, WO[3], lb_ + TB + 3 * RS * 128);           \
-  } while (0)
-
-  // fragment registers live across K-tiles (the head of a K-tile is read during the tail of its predecessor)
-  s16x8 fa[2][MT], fw[2][NTL];
-#define RD_W(SW, ks, t)                                                                                    \
-  do {                                                                                                     \
-    const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
-    fw[ks][t] = *reinterpret_cast<const s16x8*>((SW) + rw_ * 128 + swz(rw_, (ks) * 4 + fq) * 16);         \
-  } while (0)
-#define RD_A(SA, ks, t)                                                                                    \
-  do {                                                                                                     \
-    const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
-    fa[ks][t] = *reinterpret_cast<const s16x8*>((SA) + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);         \
-  } while (0)
-#define HEAD_READS(STG)                                                                                    \
-  do {                                                                                                     \
-    const char* sa_ = (STG);                                                                               \
-    const char* sw_ = sa_ + TB;                                                                            \
-    RD_W(sw_, 0, 0); RD_W(sw_, 0, 1); RD_W(sw_, 0, 2); RD_W(sw_, 0, 3);                                    \
-    RD_A(sa_, 0, 0); RD_A(sa_, 0, 1); RD_A(sa_, 0, 2); RD_A(sa_, 0, 3); RD_A(sa_, 0, 4); RD_A(sa_, 0, 5);  \
-  } while (0)
-#define MMA_GROUP(ks, gq)                                                                                  \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
-      _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
-  } while (0)
-#define PIN() __builtin_amdgcn_sched_barrier(0)
-
-  TILE_COORDS(t_lin, m0, n0);
-  TILE_OFFS(m0, n0, ao, wo);
-  PGLDS_TILE(ao, wo, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  while (true) {
-    const int t_next = t_lin + per_xcd_wg;
-    const bool has_next = t_next < xend;
-    long nm0 = 0, nn0 = 0;
-    uint32_t nao[4] = {ao[0], ao[1], ao[2], ao[3]}, nwo[4] = {wo[0], wo[1], wo[2], wo[3]};
-    if (has_next) {
-      TILE_COORDS(t_next, nm0, nn0);
-      TILE_OFFS(nm0, nn0, nao, nwo);
-    }
-    f32x4 acc[NTL][MT];
-#pragma unroll
-    for (int i = 0; i < NTL; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nkt; ++kt) {
-      // One straight-line block per K-tile, in an explicit order (PIN = sched_barrier(0)): fragment reads two 8-MFMA
-      // groups ahead of their use; the 8 LDS-DMA pieces of the next K-tile (60-180 issue cycles each) in pairs behind
-      // the first four groups instead of as a block at the top of the iteration; the last iteration fetches the next
-      // tile's first K-tile (or, for the last tile, re-fetches its own first K-tile into the idle buffer), so the body
-      // needs no branch.  (Measured and dropped: the K-tile barrier moved before the last two groups with the next
-      // K-tile's head reads issued right behind it -- 5-9 % slower in a same-box A/B.)
-      const bool lastk = kt + 1 == nkt;
-      const long kb = lastk ? 0 : (long)(kt + 1) * (BK * 2);
-      const char* ab_ = reinterpret_cast<const char*>(g.A) + kb;
-      const char* wb_ = reinterpret_cast<const char*>(g.W) + kb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ao[k] = lastk ? nao[k] : ao[k];
-        wo[k] = lastk ? nwo[k] : wo[k];
-      }
-      const int lb_ = (cur ^ 1) * STAGE + wu * 1024;
-      const char* sa = smem + cur * STAGE;
-      const char* sw = sa + TB;
-      HEAD_READS(sa);
-      PIN();
-      MMA_GROUP(0, 0);
-      PIN();
-      RD_A(sa, 0, 6); RD_A(sa, 0, 7);
-      PGLDS_ONE(ab_, ao[0], lb_); PGLDS_ONE(ab_, ao[1], lb_ + RS * 128);
-      PIN();
-      MMA_GROUP(0, 1);
-      PIN();
-      RD_W(sw, 1, 0); RD_W(sw, 1, 1); RD_W(sw, 1, 2); RD_W(sw, 1, 3); RD_A(sa, 1, 0); RD_A(sa, 1, 1);
-      PGLDS_ONE(ab_, ao[2], lb_ + 2 * RS * 128); PGLDS_ONE(ab_, ao[3], lb_ + 3 * RS * 128);
-      PIN();
-      MMA_GROUP(0, 2);
-      PIN();
-      RD_A(sa, 1, 2); RD_A(sa, 1, 3);
-      PGLDS_ONE(wb_, wo[0], lb_ + TB); PGLDS_ONE(wb_, wo[1], lb_ + TB + RS * 128);
-      PIN();
-      MMA_GROUP(0, 3);
-      PIN();
-      RD_A(sa, 1, 4); RD_A(sa, 1, 5);
-      PGLDS_ONE(wb_, wo[2], lb_ + TB + 2 * RS * 128); PGLDS_ONE(wb_, wo[3], lb_ + TB + 3 * RS * 128);
-      PIN();
-      MMA_GROUP(1, 0);
-      PIN();
-      RD_A(sa, 1, 6); RD_A(sa, 1, 7);
-      PIN();
-      MMA_GROUP(1, 1);
-      PIN();
-      MMA_GROUP(1, 2);
-      MMA_GROUP(1, 3);
-      PIN();
-#if defined(MGX_TIMING_ONLY_NO_KTILE_SYNC)  /* diagnostic builds (wrong results): what the per-K-tile rendezvous costs */
-#elif defined(MGX_TIMING_ONLY_NO_VMCNT)
-      __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0) only */
-      __builtin_amdgcn_s_barrier();
-#elif defined(MGX_TIMING_ONLY_NO_BARRIER)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-#endif
-      cur ^= 1;
-    }
-    // the epilogue touches no LDS: the next tile's K-loop (whose first K-tile is already resident) follows directly.
-    // Its lane-dependent addressing starts from opaque copies so that none of it is computed before the K-loop and
-    // kept alive across it (the loop runs at the 256-VGPR limit; a reload inside it also drains the DMA queue).
-    int el = lane, ew = wid;
-    asm volatile("" : "+v"(el), "+v"(ew));
-    persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
-    if (!has_next) break;
-    t_lin = t_next;
-    m0 = nm0; n0 = nn0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
-  }
-#undef TILE_COORDS
-#undef TILE_OFFS
-#undef PGLDS_ONE
-#undef PGLDS_TILE
-#undef RD_W
-#undef RD_A
-#undef HEAD_READS
-#undef MMA_GROUP
-#undef PIN
-}
-
-// Deeper staging variant (MGX_GEMM_MODE=6): all 160 KiB of LDS as THREE 32 KiB stages for A and TWO for W.  The A pieces of
-// K-tile k+2 and the W pieces of K-tile k+1 are issued in iteration k, W first; the end-of-iteration wait is a counted
-// `vmcnt(4)` that leaves the four A pieces (the youngest) in flight, so the activation operand -- streamed from HBM -- gets
-// two K-tiles of lead and only the weight operand (L2 / Infinity-Cache resident) has to land within one.  Raw s_barrier:
-// __syncthreads() would drain the DMA queue.  Needs K >= 128.
-template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_persist3_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
   constexpr int WBASE = 3 * TB;                   // LDS: A stages at 0, TB, 2 TB; W stages at 3 TB, 4 TB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1030,18 +835,15 @@ int launch(const GemmArgs& g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void*)gemm_persist3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
-  // MGX_GEMM_MODE: 6 (default) = persistent kernel with 3 A + 2 W stages, 4 = persistent kernel with 2 + 2 stages,
-  // 0 = the 128x128 kernel everywhere (A/B and debugging)
+  // MGX_GEMM_MODE=0 forces the 128x128 kernel everywhere (A/B and debugging)
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 6;
-  if (big && (mode == 4 || mode == 6) && g.span32) {
+  if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    if (mode == 6 && g.K >= 2 * BK) gemm_persist3_kernel<EPI><<<grid, 512, 163840, st>>>(g);
-    else gemm_persist_kernel<EPI><<<grid, 512, 131072, st>>>(g);
+    gemm_persist_kernel<EPI><<<grid, 512, 163840, st>>>(g);
   } else {
     gemm_kernel<EPI><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
