@@ -669,8 +669,12 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
     }                                                                                      \
   } while (0)
+#ifdef MGX_TIMING_ONLY_NO_DMA             /* diagnostic build (wrong results): no operand staging in the K-loop */
+#define PGLDS_ONE(base, off, off_lds) asm volatile("" :: "v"(off))
+#else
 #define PGLDS_ONE(base, off, off_lds) \
   __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
+#endif
 #define DMA_A(AO, kt_, slot_)                                                                                  \
   do {                                                                                                        \
     const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)(kt_) * (BK * 2);                            \
@@ -688,6 +692,10 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 
   // fragment registers live across K-tiles (the head of a K-tile is read during the tail of its predecessor)
   s16x8 fa[2][MT], fw[2][NTL];
+#ifdef MGX_TIMING_ONLY_NO_FRAG_READS      /* diagnostic build (wrong results): MFMAs on stale fragment registers */
+#define RD_W(SW, ks, t) asm volatile("" : "+v"(fw[ks][t]))
+#define RD_A(SA, ks, t) asm volatile("" : "+v"(fa[ks][t]))
+#else
 #define RD_W(SW, ks, t)                                                                                    \
   do {                                                                                                     \
     const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
@@ -698,6 +706,7 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
     fa[ks][t] = *reinterpret_cast<const s16x8*>((SA) + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);         \
   } while (0)
+#endif
 #define HEAD_READS3(SA_, SW_)                                                                              \
   do {                                                                                                     \
     const char* sa_ = (SA_);                                                                               \
