@@ -132,8 +132,17 @@ def main():
     def one_step():
         window = states.get_current_timesteps()
         states.update_iteration()
+        trace = {} if os.environ.get("MGX_BENCH_TRACE") else None      # debugging aid: per-pair log-prob drift to stderr
         out = TG.train_one_step(args, dev, model, None, reward_fn, opt, sched, it, None, 1.0, window, step_no[0],
-                                {"SyntheticReward": 1.0})
+                                {"SyntheticReward": 1.0}, trace=trace)
+        if trace is not None and rank == 0:
+            lp = trace["log_probs"]
+            print(f"[trace] step {step_no[0]} adv {[round(x, 3) for x in trace['advantages'].tolist()]} grad_norms "
+                  f"{[round(x.item(), 5) for x in trace.get('grad_norms', [])]}", file=sys.stderr)
+            for (pairs, nl), gl in zip(trace["new_log_probs"], trace["g_logp"]):
+                old = torch.stack([lp[i, t] for i, t in pairs])
+                print(f"[trace]   pairs {pairs}\n[trace]   new-old {[f'{x:.2e}' for x in (nl - old).tolist()]}\n"
+                      f"[trace]   g_logp {[f'{x:.2e}' for x in gl.tolist()]}", file=sys.stderr)
         step_no[0] += 1
         return out, window
 
@@ -233,7 +242,9 @@ def main():
                 "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "hbm_reserved_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                 "hbm_free_gib": round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1),
-                "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4]} if last else None,
+                "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4],
+                              "note": "grad_norm = norm of the step's last optimizer update, 0.0 when every pair of that "
+                                      "chunk is PPO-clipped at clip_range 1e-4 (DESIGN.md section 6)"} if last else None,
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -284,6 +284,8 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
                                  trace, need_grad=not dead)
         if len(chunk) == accum:                                # optimizer step every `accum` samples (:605-609)
             grad_norm = _fused_step(transformer, optimizer, max_grad_norm)
+            if trace is not None:
+                trace.setdefault("grad_norms", []).append(grad_norm.clone())
             lr_scheduler.step()
             optimizer.zero_grad()
     allreduce_mean_vec_(log)                                   # one collective for the four logging averages
