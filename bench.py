@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--skip-dead-backward", action="store_true",
                     help="do not execute the backward passes of the G %% accum leftover samples, whose gradients the "
                          "reference computes and discards (identical outputs; NOT the default, NOT the headline number)")
+    ap.add_argument("--attention", default="bf16", choices=["bf16", "fp8"],
+                    help="attention forward dtype; fp8 = the e4m3 MFMA path of BASELINE.json configs[4] (NOT the headline "
+                         "configuration: the line's dtype then reads bf16+fp8attn)")
     ap.add_argument("--gemm-shapes", default=None, help="write the per-shape GEMM time table of the roofline step here")
     a = ap.parse_args()
 
@@ -100,7 +103,7 @@ def main():
 
     wl = WORKLOADS[a.workload]
     cfg = FluxConfig(num_layers=wl["layers"][0], num_single_layers=wl["layers"][1], num_attention_heads=wl["heads"])
-    model = FluxTransformer2DModel(cfg, device=dev).init_synthetic(seed=0, std=0.02)
+    model = FluxTransformer2DModel(cfg, device=dev, attention_dtype=a.attention).init_synthetic(seed=0, std=0.02)
     opt = FusedAdamW(model, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     sched = ConstantWithWarmup(opt, 0)
     args = TG.default_args(h=wl["h"], w=wl["w"], sampling_steps=wl["sampling_steps"], num_generations=wl["num_generations"],
@@ -229,7 +232,8 @@ def main():
     if rank == 0:
         line = {"metric": "GRPO train-step images/sec, FLUX.1-dev 1024^2", "value": round(value, 5), "unit": "images/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 1),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.attention == "bf16" else "bf16+fp8attn",
+                "data": "synthetic",
                 "config": {"workload": a.workload, "model": "FLUX.1-dev (random-init, 11.9B)" if wl["layers"] == (19, 38)
                            else f"FLUX-like {wl['layers']} blocks", "resolution": f"{args.h}x{args.w}",
                            "sampling_steps": T, "sde_window": last[1] if last else None, "group_size": G,

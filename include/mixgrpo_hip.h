@@ -183,6 +183,19 @@ int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const fl
 int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H, int S,
                  int Sp, long ldo, long o_bstride, float scale, void* stream);
 
+/* fp8 (OCP e4m3) variant of mgx_attn_fwd: the "fp8 MFMA attention path" of BASELINE.json configs[4].  The reference
+ * has no fp8 attention; the entry points serve the same SDPA call sites (fastvideo/utils/sampling_utils.py:68-82,
+ * train_grpo_flux.py:134-144).
+ * mgx_attn_fp8_quantize: amax [3][B*H] fp32 (|max| of Q, K, V per batch-head, V over the S valid keys), Q8/K8
+ * [B,H,S,128] = e4m3(x * 448 / amax), V8t [B,H,128,Sp] likewise with the keys of every 64-key block in the order
+ * p = 32h + 16kb + i  <-  key 32kb + 8(i>>2) + 4h + (i&3)  (the order the kernel's P^T fragment holds them).
+ * mgx_attn_fwd_fp8: O, lse as mgx_attn_fwd from the quantised operands (both contractions on e4m3 MFMA, P in e4m3,
+ * fp32 statistics / accumulators).  The backward stays mgx_attn_bwd on the bf16 operands with this O / lse. */
+int mgx_attn_fp8_quantize(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint8_t* Q8, uint8_t* K8,
+                          uint8_t* V8t, float* amax, int B, int H, int S, int Sp, void* stream);
+int mgx_attn_fwd_fp8(const uint8_t* Q8, const uint8_t* K8, const uint8_t* V8t, const float* amax, uint16_t* O,
+                     float* lse, int B, int H, int S, int Sp, long ldo, long o_bstride, float scale, void* stream);
+
 /* Backward of mgx_attn_fwd (P recomputed from lse): dQ, dK, dV [B,H,S,128].  Inputs Q,K,V row-major, Qt,Kt
  * [B,H,128,Sp] (mgx_qk_norm_rope_fwd extras), O and dO [B,S,ldo] at column h*128.  delta [B,H,S] fp32 and dOt
  * [B,H,128,Sp] bf16 are caller-provided scratch filled by the internal prep kernel. */

@@ -202,6 +202,17 @@ class _Work:
         self.out = e(B, N, cfg.patch_size * cfg.patch_size * cfg.in_channels)
         self.lse = e(B, H, S, dtype=F32)
         self.train = None                         # flux_backward._Train, at its own batch capacity
+        self._f8 = None                           # (Q8, K8, V8t, amax): allocated when attention_dtype == "fp8"
+        self._dims = (H, hd)
+
+    def fp8_operands(self):
+        """e4m3 copies of Q, K and the key-permuted V^T plus the per-(batch, head) amax table, at batch capacity."""
+        if self._f8 is None:
+            H, hd = self._dims
+            u8 = lambda *shape: torch.empty(*shape, dtype=torch.uint8, device=self.X.device)
+            self._f8 = (u8(self.B, H, self.S, hd), u8(self.B, H, self.S, hd), u8(self.B, H, hd, self.Sp),
+                        torch.empty(3 * self.B * H, dtype=F32, device=self.X.device))
+        return self._f8
 
     def view(self, B):
         return self if B == self.B else _WorkView(self, B)
@@ -218,6 +229,10 @@ class _WorkView:
         self.nrm, self.qkv, self.hid = base.nrm[:M], base.qkv[:M], base.hid[:M]
         self.in16, self.out, self.lse = base.in16[:B * base.N], base.out[:B], base.lse[:B]
 
+    def fp8_operands(self):
+        q8, k8, v8t, amax = self.base.fp8_operands()
+        return q8[:self.B], k8[:self.B], v8t[:self.B], amax      # amax is laid out [3][B*H] for the CURRENT batch
+
     @property
     def train(self):
         return self.base.train
@@ -230,8 +245,11 @@ class _WorkView:
 class FluxTransformer2DModel(torch.nn.Module):
     """MI355X-native FLUX MMDiT.  `hipflux = FluxTransformer2DModel(FluxConfig(), device="cuda")`."""
 
-    def __init__(self, config: FluxConfig = None, device="cuda", **cfg_kwargs):
+    def __init__(self, config: FluxConfig = None, device="cuda", attention_dtype="bf16", **cfg_kwargs):
         super().__init__()
+        if attention_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"attention_dtype {attention_dtype!r} is not supported (bf16 | fp8)")
+        self.attention_dtype = attention_dtype    # "fp8": e4m3 MFMA attention forward (BASELINE.json configs[4])
         self.cfg = config or FluxConfig(**cfg_kwargs)
         self.config = self.cfg.to_dict()
         dev = torch.device(device)
@@ -295,6 +313,19 @@ class FluxTransformer2DModel(torch.nn.Module):
             base = _Work(self.cfg, B, L, N, self.store.device)
             self._work[key] = base
         return base.view(B)
+
+    def _attn(self, w, O, lse, ldo, o_bstride):
+        """Joint attention of the current Q / K / Vt workspace into O (+ LSE).  `attention_dtype == "fp8"` (BASELINE.json
+        configs[4]) quantises the operands per (batch, head) to e4m3 and runs both contractions on fp8 MFMA; every
+        forward of the model (rollout, training forward) then uses it, the backward stays bf16."""
+        H, hd = self.cfg.num_attention_heads, self.cfg.attention_head_dim
+        scale = 1.0 / math.sqrt(hd)
+        if self.attention_dtype == "fp8":
+            q8, k8, v8t, amax = w.fp8_operands()
+            ops.attn_fp8_quantize(w.Q, w.K, w.Vt, q8, k8, v8t, amax, w.B, H, w.S, w.Sp)
+            ops.attn_fwd_fp8(q8, k8, v8t, amax, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
+        else:
+            ops.attn_fwd(w.Q, w.K, w.Vt, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
 
     def _rope(self, txt_ids, img_ids):
         key = (id(txt_ids), txt_ids._version, tuple(txt_ids.shape), id(img_ids), img_ids._version, tuple(img_ids.shape))
@@ -385,8 +416,7 @@ class FluxTransformer2DModel(torch.nn.Module):
             w.O.copy_(keep["O"])
             w.lse.copy_(keep["lse"])
         else:
-            ops.attn_fwd(w.Q, w.K, w.Vt, w.O, keep["lse"] if keep is not None else (w.lse if save is not None else None),
-                         B, H, w.S, w.Sp, d, w.S * d, 1.0 / math.sqrt(cfg.attention_head_dim))
+            self._attn(w, w.O, keep["lse"] if keep is not None else (w.lse if save is not None else None), d, w.S * d)
             if keep is not None:
                 keep["O"].copy_(w.O)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
@@ -449,8 +479,7 @@ class FluxTransformer2DModel(torch.nn.Module):
             w.cat[:, :, :d].copy_(keep["O"])
             w.lse.copy_(keep["lse"])
             return m
-        ops.attn_fwd(w.Q, w.K, w.Vt, w.cat, keep["lse"] if keep is not None else (w.lse if save is not None else None),
-                     B, H, S, w.Sp, 5 * d, S * 5 * d, 1.0 / math.sqrt(cfg.attention_head_dim))
+        self._attn(w, w.cat, keep["lse"] if keep is not None else (w.lse if save is not None else None), 5 * d, S * 5 * d)
         if keep is not None:
             keep["O"].copy_(w.cat[:, :, :d])
         aux = keep["y_attn"] if keep is not None else (None if save is None else save["y_attn"])

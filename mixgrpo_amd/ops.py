@@ -102,6 +102,17 @@ def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):
                              scale, stream()))
 
 
+def attn_fp8_quantize(Q, K, Vt, Q8, K8, V8t, amax, B, H, S, Sp):
+    """Per-(batch, head) e4m3 quantisation of the attention operands (csrc/attention_fp8.hip)."""
+    check(lib().mgx_attn_fp8_quantize(ptr(Q), ptr(K), ptr(Vt), ptr(Q8), ptr(K8), ptr(V8t), ptr(amax), B, H, S, Sp,
+                                      stream()))
+
+
+def attn_fwd_fp8(Q8, K8, V8t, amax, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):
+    check(lib().mgx_attn_fwd_fp8(ptr(Q8), ptr(K8), ptr(V8t), ptr(amax), O_ptr_tensor.data_ptr(), ptr(lse), B, H, S, Sp,
+                                 ldo, o_bstride, scale, stream()))
+
+
 def skinny_linear(x, W, bias, out, N, K):
     """out[b] = bf16(x[b] @ W^T + bias) for <= 16 rows per call (more rows are chunked)."""
     Bn = x.shape[0]
