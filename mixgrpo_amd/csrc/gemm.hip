@@ -714,12 +714,22 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     RD_W(sw_, 0, 0); RD_W(sw_, 0, 1); RD_W(sw_, 0, 2); RD_W(sw_, 0, 3);                                    \
     RD_A(sa_, 0, 0); RD_A(sa_, 0, 1); RD_A(sa_, 0, 2); RD_A(sa_, 0, 3); RD_A(sa_, 0, 4); RD_A(sa_, 0, 5);  \
   } while (0)
+#ifdef MGX_TIMING_ONLY_MFMA32             /* diagnostic build (wrong results): the same fragments and MFMA cycles on half as many, 32x32x16 instructions */
+#define MMA_GROUP(ks, gq)                                                                                  \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_) {                                   \
+      acc16[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][2 * (j_ & 1)], fa[ks][j_], acc16[j_], 0, 0, 0);     \
+      acc16[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][2 * (j_ & 1) + 1], fa[ks][j_], acc16[j_], 0, 0, 0); \
+    }                                                                                                      \
+  } while (0)
+#else
 #define MMA_GROUP(ks, gq)                                                                                  \
   do {                                                                                                     \
     _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
       _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
   } while (0)
+#endif
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
   TILE_COORDS(t_lin, m0, n0);
@@ -743,10 +753,18 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     // DMA source sets in use: they switch to the next tile two (A) / one (W) K-tiles before this tile ends
     uint32_t ca[4] = {ao[0], ao[1], ao[2], ao[3]}, cw[4] = {wo[0], wo[1], wo[2], wo[3]};
     f32x4 acc[NTL][MT];
+#ifdef MGX_TIMING_ONLY_MFMA32
+    f32x16 acc16[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc16[j][r] = 0.f;
+#else
 #pragma unroll
     for (int i = 0; i < NTL; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 
     for (int kt = 0; kt < nkt; ++kt) {
       const bool a_next = kt + 2 >= nkt, w_next = kt + 1 >= nkt;
@@ -817,6 +835,12 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     // kept alive across it (the loop runs at the 256-VGPR limit; a reload inside it also drains the DMA queue).
     int el = lane, ew = wid;
     asm volatile("" : "+v"(el), "+v"(ew));
+#ifdef MGX_TIMING_ONLY_MFMA32
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{acc16[j][4 * i], acc16[j][4 * i + 1], acc16[j][4 * i + 2], acc16[j][4 * i + 3]};
+#endif
     persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
     if (!has_next) break;
     t_lin = t_next;
