@@ -1,0 +1,49 @@
+"""bench.py end to end on the small stand-in workload: the one-GPU line carries the contract's fields (roofline,
+cpu_baseline), and the N = 2 launch (the driver's `python -m torch.distributed.run ... bench.py --gpus 2` form, here with
+both ranks on cuda:0 over gloo) runs its collectives to completion and reports the whole-job rate.  Guards the
+distributed path of the bench against rank-asymmetric code (a rank-0-only train step deadlocks the gradient all-reduce)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    rows = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(rows) == 1, out[-2000:]
+    return json.loads(rows[0])
+
+
+def test_bench_one_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "tiny_256_T8_W2_G4", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0
+    assert j["unit"] == "images/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert abs(j["value"] - 4 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3          # G = 4 images per step
+    rf, cb = j["roofline"], j["cpu_baseline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["achieved"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, MGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                        "--workload", "tiny_256_T8_W2_G4", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 8
+    assert abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3          # both ranks' images over the max time
+    assert j["cpu_baseline"] is None                                                   # reported at N = 1 only
+    assert j["last_step"]["loss"] == j["last_step"]["loss"]
