@@ -690,30 +690,41 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
     PGLDS_ONE(wb_, WO[3], lb_ + 3 * RS * 128);                                                                \
   } while (0)
 
-  // fragment registers live across K-tiles (the head of a K-tile is read during the tail of its predecessor)
+  // Fragment reads are inline asm with hand-counted `lgkmcnt` waits.  With LDS-DMA instructions in the loop hipcc's
+  // wait-count pass treats the LDS counter as out of order and turns every wait for a `ds_read` into `lgkmcnt(0)`: the ten
+  // head reads of a K-tile (80 KiB per workgroup, right after the barrier) had to drain completely before the first MFMA,
+  // and reads issued two MFMA groups ahead were drained one group after their issue.  The schedule below is pinned anyway,
+  // so the counts are static: N = number of reads issued after the youngest one the next MFMA needs.
   s16x8 fa[2][MT], fw[2][NTL];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+  uint32_t a_ro[2], w_ro[2];                       // lane offsets inside a stage: row, swizzled 16-byte chunk of k-step ks
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_ro[ks] = (uint32_t)((wm * 128 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
+    w_ro[ks] = (uint32_t)((wn * 64 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
+  }
 #ifdef MGX_TIMING_ONLY_NO_FRAG_READS      /* diagnostic build (wrong results): MFMAs on stale fragment registers */
-#define RD_W(SW, ks, t) asm volatile("" : "+v"(fw[ks][t]))
-#define RD_A(SA, ks, t) asm volatile("" : "+v"(fa[ks][t]))
+#define RD_W(ks, t) asm volatile("" : "+v"(fw[ks][t]))
+#define RD_A(ks, t) asm volatile("" : "+v"(fa[ks][t]))
+#elif defined(MGX_GEMM_COMPILER_WAITS)    /* A/B build: plain loads, hipcc's own (all lgkmcnt(0)) waits */
+#define RD_W(ks, t) fw[ks][t] = *reinterpret_cast<const s16x8*>(smem + (w_ad[ks] - lds0) + (t) * 2048)
+#define RD_A(ks, t) fa[ks][t] = *reinterpret_cast<const s16x8*>(smem + (a_ad[ks] - lds0) + (t) * 2048)
 #else
-#define RD_W(SW, ks, t)                                                                                    \
-  do {                                                                                                     \
-    const int rw_ = wn * 64 + (t) * 16 + fr;                                                               \
-    fw[ks][t] = *reinterpret_cast<const s16x8*>((SW) + rw_ * 128 + swz(rw_, (ks) * 4 + fq) * 16);         \
-  } while (0)
-#define RD_A(SA, ks, t)                                                                                    \
-  do {                                                                                                     \
-    const int ra_ = wm * 128 + (t) * 16 + fr;                                                              \
-    fa[ks][t] = *reinterpret_cast<const s16x8*>((SA) + ra_ * 128 + swz(ra_, (ks) * 4 + fq) * 16);         \
-  } while (0)
+#define RD_W(ks, t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ks][t]) : "v"(w_ad[ks]), "n"((t) * 2048))
+#define RD_A(ks, t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[ks][t]) : "v"(a_ad[ks]), "n"((t) * 2048))
 #endif
-#define HEAD_READS3(SA_, SW_)                                                                              \
-  do {                                                                                                     \
-    const char* sa_ = (SA_);                                                                               \
-    const char* sw_ = (SW_);                                                                               \
-    RD_W(sw_, 0, 0); RD_W(sw_, 0, 1); RD_W(sw_, 0, 2); RD_W(sw_, 0, 3);                                    \
-    RD_A(sa_, 0, 0); RD_A(sa_, 0, 1); RD_A(sa_, 0, 2); RD_A(sa_, 0, 3); RD_A(sa_, 0, 4); RD_A(sa_, 0, 5);  \
-  } while (0)
+#ifdef MGX_GEMM_COMPILER_WAITS
+#define WAIT1(n, x0) do {} while (0)
+#define WAIT2(n, x0, x1) do {} while (0)
+#define WAIT6(n, x0, x1, x2, x3, x4, x5) do {} while (0)
+#else
+#define WAIT1(n, x0) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0))
+#define WAIT2(n, x0, x1) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0), "+v"(x1))
+#define WAIT6(n, x0, x1, x2, x3, x4, x5) \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5))
+#endif
+#define MMA1(ks, i_, j_) \
+  acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0)
 #ifdef MGX_TIMING_ONLY_MFMA32             /* diagnostic build (wrong results): the same fragments and MFMA cycles on half as many, 32x32x16 instructions */
 #define MMA_GROUP(ks, gq)                                                                                  \
   do {                                                                                                     \
@@ -777,42 +788,61 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       }
       const int a_dst = aslot == 0 ? 2 : aslot - 1;     // (aslot + 2) % 3
       const int w_dst = wslot ^ 1;
-      const char* sa = smem + aslot * TB;
-      const char* sw = smem + WBASE + wslot * TB;
       const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)akt * (BK * 2);
       const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)wkt * (BK * 2);
       const int la_ = a_dst * TB + wu * 1024, lw_ = WBASE + w_dst * TB + wu * 1024;
-      HEAD_READS3(sa, sw);
+      const uint32_t sa_u = lds0 + aslot * TB, sw_u = lds0 + WBASE + wslot * TB;
+      const uint32_t a_ad[2] = {sa_u + a_ro[0], sa_u + a_ro[1]}, w_ad[2] = {sw_u + w_ro[0], sw_u + w_ro[1]};
       // the four W pieces first thing (they must land within this iteration: every cycle of lead counts, +2-7 %)
       PGLDS_ONE(wb_, cw[0], lw_); PGLDS_ONE(wb_, cw[1], lw_ + RS * 128);
       PGLDS_ONE(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_ONE(wb_, cw[3], lw_ + 3 * RS * 128);
       PIN();
+      // head reads r1..r10, the two the first MFMA needs in front
+      RD_W(0, 0); RD_A(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3); RD_A(0, 1);
+      RD_A(0, 2); RD_A(0, 3); RD_A(0, 4); RD_A(0, 5);
+      PIN();
+#ifdef MGX_TIMING_ONLY_MFMA32
       MMA_GROUP(0, 0);
+#else
+      WAIT2(8, fw[0][0], fa[0][0]); MMA1(0, 0, 0); PIN();
+      WAIT1(7, fw[0][1]); MMA1(0, 1, 0); PIN();
+      WAIT1(6, fw[0][2]); MMA1(0, 2, 0); PIN();
+      WAIT1(5, fw[0][3]); MMA1(0, 3, 0); PIN();
+      WAIT1(4, fa[0][1]); MMA1(0, 0, 1); MMA1(0, 1, 1); MMA1(0, 2, 1); MMA1(0, 3, 1);
+#endif
       PIN();
-      RD_A(sa, 0, 6); RD_A(sa, 0, 7);
+      RD_A(0, 6); RD_A(0, 7);                                           // r11, r12
       PIN();
+      WAIT2(4, fa[0][2], fa[0][3]);                                     // r7, r8 (r9..r12 may be in flight)
       MMA_GROUP(0, 1);
       PIN();
-      RD_W(sw, 1, 0); RD_W(sw, 1, 1); RD_W(sw, 1, 2); RD_W(sw, 1, 3); RD_A(sa, 1, 0); RD_A(sa, 1, 1);
+      RD_W(1, 0); RD_W(1, 1); RD_W(1, 2); RD_W(1, 3); RD_A(1, 0); RD_A(1, 1);   // r13..r18
       PIN();
+      WAIT2(8, fa[0][4], fa[0][5]);                                     // r9, r10
       MMA_GROUP(0, 2);
       PIN();
-      RD_A(sa, 1, 2); RD_A(sa, 1, 3);
+      RD_A(1, 2); RD_A(1, 3);                                           // r19, r20
       // the four A pieces (two K-tiles of lead) in pairs behind MFMA groups (all eight at the top: 6-9 % slower)
       PGLDS_ONE(ab_, ca[0], la_); PGLDS_ONE(ab_, ca[1], la_ + RS * 128);
       PIN();
+      WAIT2(8, fa[0][6], fa[0][7]);                                     // r11, r12
       MMA_GROUP(0, 3);
       PIN();
-      RD_A(sa, 1, 4); RD_A(sa, 1, 5);
+      RD_A(1, 4); RD_A(1, 5);                                           // r21, r22
       PGLDS_ONE(ab_, ca[2], la_ + 2 * RS * 128); PGLDS_ONE(ab_, ca[3], la_ + 3 * RS * 128);
       PIN();
+      WAIT6(4, fw[1][0], fw[1][1], fw[1][2], fw[1][3], fa[1][0], fa[1][1]);   // r13..r18
       MMA_GROUP(1, 0);
       PIN();
-      RD_A(sa, 1, 6); RD_A(sa, 1, 7);
+      RD_A(1, 6); RD_A(1, 7);                                           // r23, r24
       PIN();
+      WAIT2(4, fa[1][2], fa[1][3]);                                     // r19, r20
       MMA_GROUP(1, 1);
       PIN();
+      WAIT2(2, fa[1][4], fa[1][5]);                                     // r21, r22
       MMA_GROUP(1, 2);
+      PIN();
+      WAIT2(0, fa[1][6], fa[1][7]);                                     // r23, r24
       MMA_GROUP(1, 3);
       PIN();
       // everything but the four A pieces issued in this iteration has landed: the next K-tile's W (this iteration) and A
@@ -855,7 +885,10 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #undef DMA_W
 #undef RD_W
 #undef RD_A
-#undef HEAD_READS3
+#undef WAIT1
+#undef WAIT2
+#undef WAIT6
+#undef MMA1
 #undef MMA_GROUP
 #undef PIN
 }
