@@ -1,7 +1,7 @@
 // bf16 MFMA GEMM for the MMDiT linears (gfx950):  C[M,N] = epi( A[M,K] @ W[N,K]^T + bias )
 //
 // Both operands are K-contiguous ("NT"): activations [tokens, features] and torch Linear weights [out, in].
-// Two kernels: `gemm_persist_kernel` (256x256x64 tiles, persistent, LDS-DMA staging: every problem with >= 192 such tiles,
+// Two kernels: `gemm_persist_kernel` (256x256x64 tiles, persistent, LDS-DMA staging: every problem with >= 128 such tiles,
 // i.e. all the FLOPs that matter; described at its definition) and `gemm_kernel` for the small problems:
 // tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16
 // accumulators.  Operands are staged global -> registers -> LDS (issue-early / write-late, one barrier per
@@ -895,9 +895,11 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t st) {
-  // the 256x256 tile needs enough tiles to fill 256 CUs; skinny / small problems keep the 128x128 tile
+  // the 256x256 tile needs enough tiles to fill most of the 256 CUs; skinny / small problems keep the 128x128 tile
+  // (measured, scratch/bench_gemm_small.py: 168 tiles 843-935 vs 591-691 TFLOP/s, 120 tiles equal, 24-96 tiles slower)
   const long tiles_big = (long)cdiv(g.M, 256) * cdiv(g.N, 256);
-  const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= 192 && (g.N % 256 == 0 || g.N >= 2048);
+  static const long min_tiles = getenv("MGX_GEMM_BIG_MIN_TILES") ? atol(getenv("MGX_GEMM_BIG_MIN_TILES")) : 128;
+  const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= min_tiles && (g.N % 256 == 0 || g.N >= 2048);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);

@@ -1,5 +1,5 @@
 """GPU parity of `mgx_gemm_bf16` (csrc/gemm.hip) against a plain fp32 torch reference of the same op, through the
-C ABI.  The shapes are chosen so that BOTH kernel families run: the persistent 256x256 kernel (>= 192 tiles) and the
+C ABI.  The shapes are chosen so that BOTH kernel families run: the persistent 256x256 kernel (>= 128 tiles) and the
 128x128 kernel (small problems), with ragged M / N edges, row-batched A and C operands whose batch boundaries fall
 inside tiles, and every fused epilogue.
 
@@ -48,7 +48,7 @@ def _close_bf16(out, ref, y=None, amp=0.0):
     assert (out != ref).float().mean().item() < 0.02
 
 
-# (M, N, K): persistent kernel needs ceil(M/256)*ceil(N/256) >= 192 and (N % 256 == 0 or N >= 2048)
+# (M, N, K): persistent kernel needs ceil(M/256)*ceil(N/256) >= 128 and (N % 256 == 0 or N >= 2048)
 BIG = [(4096 + 37, 3072, 192), (6000, 2624, 128), (256 * 24, 2048, 64)]
 SMALL = [(200, 136, 192), (1000, 64, 256), (513, 1032, 64)]
 
