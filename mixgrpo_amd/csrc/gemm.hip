@@ -603,11 +603,19 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
         if ((EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GATE_RES) && g.aux) {
           char* ab = const_cast<char*>(abase);      // pre-activation / pre-gate branch output for the backward pass
           const uint32_t ao = (uint32_t)r * lda2;
+#ifdef MGX_TIMING_ONLY_NO_EPI_STORES     /* diagnostic build (wrong results): the epilogue's loads and arithmetic without its stores */
+          asm volatile("" :: "v"(y[j][0].x), "v"(y[j][0].y), "v"(y[j][0].z), "v"(y[j][0].w), "v"(y[j][1].x), "v"(y[j][1].y),
+                       "v"(y[j][1].z), "v"(y[j][1].w), "v"(ab), "v"(ao));
+        }
+        asm volatile("" :: "v"(o[jj][0].x), "v"(o[jj][0].y), "v"(o[jj][0].z), "v"(o[jj][0].w), "v"(o[jj][1].x), "v"(o[jj][1].y),
+                     "v"(o[jj][1].z), "v"(o[jj][1].w), "v"(cb), "v"(co));
+#else
           if (nok0) *reinterpret_cast<uint4*>(ab + (ao + c0)) = y[j][0];
           if (nok1) *reinterpret_cast<uint4*>(ab + (ao + c1)) = y[j][1];
         }
         if (nok0) *reinterpret_cast<uint4*>(cb + (co + c0)) = o[jj][0];
         if (nok1) *reinterpret_cast<uint4*>(cb + (co + c1)) = o[jj][1];
+#endif
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -871,7 +879,14 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{acc16[j][4 * i], acc16[j][4 * i + 1], acc16[j][4 * i + 2], acc16[j][4 * i + 3]};
 #endif
+#ifdef MGX_TIMING_ONLY_NO_EPILOGUE        /* diagnostic build (wrong results): what the register epilogue costs in situ */
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) asm volatile("" :: "v"(acc[i][j]));
+#else
     persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
+#endif
     if (!has_next) break;
     t_lin = t_next;
     m0 = nm0; n0 = nn0;
