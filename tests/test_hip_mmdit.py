@@ -212,3 +212,55 @@ def test_attention_backward_vs_torch():
     assert rel_err(dV, vf.grad) < 1e-2
     assert rel_err(dK, kf.grad) < 1.5e-2
     assert rel_err(dQ, qf.grad) < 1.5e-2
+
+
+def test_attention_full_size_properties():
+    """BASELINE-size attention (H = 24, S = 4608 = 512 text + 4096 image tokens, head_dim 128) through properties that do
+    not need a full-size reference: rows of P sum to one (V = 1 gives O = 1 exactly), sampled query rows against an fp32
+    torch reference, invariance under a joint permutation of the keys and values, and for the backward the scale identity
+    sum_i <q_i, dq_i> = sum_j <k_j, dk_j> (both equal sum_ij P_ij dS_ij s_ij) plus sampled rows of dV."""
+    from mixgrpo_amd import ops
+    B, H, S = 1, 24, 4608
+    Sp = S
+    sc = 1 / math.sqrt(128)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16()
+
+    def fwd(q_, k_, v_):
+        O = torch.empty(B, S, H * 128, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, S, device="cuda")
+        ops.attn_fwd(q_, k_, v_.transpose(-1, -2).contiguous(), O, lse, B, H, S, Sp, H * 128, S * H * 128, sc)
+        return O.view(B, S, H, 128).permute(0, 2, 1, 3), lse
+
+    ones = torch.ones_like(v)
+    O1, _ = fwd(q, k, ones)
+    assert torch.equal(O1.float(), torch.ones_like(O1).float())                    # sum_j P_ij = 1, exactly 1.0 in bf16
+    O, lse = fwd(q, k, v)
+    rows = torch.randint(0, S, (96,), generator=torch.Generator().manual_seed(1)).cuda()
+    s = (q[:, :, rows].float() @ k.float().transpose(-1, -2)) * sc                 # [B, H, 96, S]
+    ref = torch.softmax(s, -1) @ v.float()
+    assert rel_err(O[:, :, rows], ref) < 6e-3
+    assert torch.allclose(lse[:, :, rows], torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(2)).cuda()
+    Op, lsep = fwd(q, k[:, :, perm].contiguous(), v[:, :, perm].contiguous())
+    assert rel_err(Op, O.float()) < 4e-3 and torch.allclose(lsep, lse, rtol=1e-5, atol=1e-5)   # only the summation order moved
+
+    do = torch.randn(B, S, H * 128, device="cuda", generator=g).bfloat16()
+    Oc = O.permute(0, 2, 1, 3).reshape(B, S, H * 128).contiguous()
+    tr = lambda t: t.transpose(-1, -2).contiguous()
+    dQ, dK, dV = (torch.empty_like(q) for _ in range(3))
+    delta = torch.empty(B, H, S, device="cuda")
+    dOt = torch.zeros(B, H, 128, Sp, device="cuda", dtype=torch.bfloat16)
+    ops.attn_bwd(q, k, v, tr(q), tr(k), Oc, do, lse, delta, dOt, dQ, dK, dV, B, H, S, Sp, H * 128, S * H * 128, sc)
+    torch.cuda.synchronize()
+    lhs = (q.double() * dQ.double()).sum(dim=(2, 3))
+    rhs = (k.double() * dK.double()).sum(dim=(2, 3))
+    assert torch.allclose(lhs, rhs, rtol=2e-2, atol=2e-2 * lhs.abs().mean().item()), (lhs - rhs).abs().max()
+    # dV[j] = sum_i P_ij dO_i on sampled keys (P from the fp32 reference scores of ALL queries against those keys)
+    keys = rows[:32]
+    dOh = do.view(B, S, H, 128).permute(0, 2, 1, 3).float()
+    sk = (q.float() @ k[:, :, keys].float().transpose(-1, -2)) * sc                # [B, H, S, 32]
+    Pk = torch.exp(sk - lse.unsqueeze(-1))
+    assert rel_err(dV[:, :, keys], Pk.transpose(-1, -2) @ dOh) < 1.5e-2
