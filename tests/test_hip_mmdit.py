@@ -264,3 +264,48 @@ def test_attention_full_size_properties():
     sk = (q.float() @ k[:, :, keys].float().transpose(-1, -2)) * sc                # [B, H, S, 32]
     Pk = torch.exp(sk - lse.unsqueeze(-1))
     assert rel_err(dV[:, :, keys], Pk.transpose(-1, -2) @ dOh) < 1.5e-2
+
+
+def test_full_width_blocks_vs_oracle():
+    """BASELINE.json configs[0] geometry at FULL width: d = 3072 (24 heads x 128), joint_attention_dim 4096, pooled 768,
+    1 double + 1 single block, N = 1024 image tokens (64x64 latent) + 512 text tokens.  Everything the FLUX.1-dev step
+    runs is on this path at its real width (persistent 256x256 GEMM with every epilogue, fused QKV views, full RoPE axes,
+    24-head attention forward / backward, wgrad / dgrad shapes); forward and parameter gradients against the CPU oracle."""
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    kw = dict(num_layers=1, num_single_layers=1)                     # every other field: the FLUX.1-dev default
+    ocfg = OM.FluxConfig(**kw)
+    P = OM.init_params(ocfg, seed=2, std=0.02, bias_std=0.02)
+    m = FluxTransformer2DModel(FluxConfig(**kw), device="cuda")
+    m.load_state_dict({k: v.cuda() for k, v in P.items()})
+    g = torch.Generator().manual_seed(4)
+    B, hg, wg, L = 1, 32, 32, 512
+    N = hg * wg
+    x = torch.randn(B, N, 64, generator=g)
+    ehs = (0.1 * torch.randn(B, L, 4096, generator=g)).bfloat16()
+    pooled = torch.randn(B, 768, generator=g).bfloat16()
+    ids = torch.zeros(hg, wg, 3)
+    ids[..., 1] += torch.arange(hg)[:, None]
+    ids[..., 2] += torch.arange(wg)[None]
+    ids = ids.reshape(N, 3)
+    tids, t, gd = torch.zeros(L, 3), torch.tensor([0.954]), torch.tensor([3.5]).bfloat16()
+    R = torch.randn(B, N, 64, generator=g)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = OM.forward(Pg, ocfg, x, ehs.float(), t, gd.float(), tids, pooled.float(), ids)
+    (ref * R).sum().backward()
+    m.train()
+    out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
+    assert rel_err(out, ref) < 1e-2
+    (out.float() * R.cuda()).sum().backward()
+    gbuf = m.store.g32
+    dots = nh = no = 0.0
+    worst = []
+    for k in P:
+        gh = m.store.view(gbuf, k).float().cpu()
+        go = Pg[k].grad
+        dots += (gh * go).sum().item()
+        nh += gh.pow(2).sum().item()
+        no += go.pow(2).sum().item()
+        worst.append((((gh - go).norm() / (go.norm() + 1e-9)).item(), k))
+    worst.sort(reverse=True)
+    assert dots / math.sqrt(nh * no) > 0.999, (dots / math.sqrt(nh * no), worst[:5])
+    assert worst[0][0] < 5e-2, worst[:8]
