@@ -38,3 +38,29 @@ def assert_same(a, b, exact=True, rtol=2e-6, atol=2e-6):
         fin = torch.isfinite(b)
         assert torch.equal(a[~fin & ~torch.isnan(b)], b[~fin & ~torch.isnan(b)])
         assert torch.allclose(a[fin].float(), b[fin].float(), rtol=rtol, atol=atol), (a[fin].float() - b[fin].float()).abs().max()
+
+
+def oracle_flux(cfg, P):
+    """oracle/mmdit.forward behind the transformer call signature, parameters trainable (fp32 master weights; the
+    restatement rounds to bf16 where autocast does).  Used by the end-to-end tests on both the CPU and the GPU side."""
+    import torch
+    from oracle import mmdit as OM
+
+    class OracleFlux(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cfg, self.names = cfg, list(P)
+            self.params = torch.nn.ParameterList([torch.nn.Parameter(P[k].clone()) for k in self.names])
+            self.config = {"oracle": True}
+
+        def forward(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids, pooled_projections, img_ids,
+                    joint_attention_kwargs=None, return_dict=False):
+            Pd = dict(zip(self.names, self.params))
+            out = OM.forward(Pd, self.cfg, hidden_states.float(), encoder_hidden_states.float(), timestep.float(),
+                             guidance.float(), txt_ids.float(), pooled_projections.float(), img_ids.float())
+            return (out.to(torch.bfloat16),)
+
+        def clip_grad_norm_(self, max_norm):
+            return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
+
+    return OracleFlux()

@@ -13,6 +13,7 @@ from argparse import Namespace
 import pytest
 import torch
 
+from helpers import oracle_flux
 from oracle import mmdit as OM
 from oracle import trainer as OT
 
@@ -20,27 +21,6 @@ pytestmark = pytest.mark.gpu
 
 KW = dict(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=4, joint_attention_dim=64,
           pooled_projection_dim=32)
-
-
-class OracleFlux(torch.nn.Module):
-    """oracle/mmdit.forward behind the transformer call signature, parameters trainable (fp32 master weights; the
-    restatement rounds to bf16 where autocast does)."""
-
-    def __init__(self, cfg, P):
-        super().__init__()
-        self.cfg, self.names = cfg, list(P)
-        self.params = torch.nn.ParameterList([torch.nn.Parameter(P[k].clone()) for k in self.names])
-        self.config = {"oracle": True}
-
-    def forward(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids, pooled_projections, img_ids,
-                joint_attention_kwargs=None, return_dict=False):
-        P = dict(zip(self.names, self.params))
-        out = OM.forward(P, self.cfg, hidden_states.float(), encoder_hidden_states.float(), timestep.float(),
-                         guidance.float(), txt_ids.float(), pooled_projections.float(), img_ids.float())
-        return (out.to(torch.bfloat16),)
-
-    def clip_grad_norm_(self, max_norm):
-        return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
 
 
 class _Sched:
@@ -76,7 +56,7 @@ def test_train_step_with_mmdit_vs_oracle():
 
     ocfg = OM.FluxConfig(**KW)
     P = OM.init_params(ocfg, seed=3, std=0.05, bias_std=0.02)
-    mo = OracleFlux(ocfg, P)
+    mo = oracle_flux(ocfg, P)
     oo = torch.optim.AdamW(mo.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     mp = FluxTransformer2DModel(FluxConfig(**KW), device=dev)
     mp.load_state_dict({k: t.to(dev) for k, t in P.items()})
