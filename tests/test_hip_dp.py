@@ -29,12 +29,13 @@ def _one_step(rank, world, seed_prompt):
            "steps": [torch.randn(4, 12, 64, generator=g).bfloat16() for _ in range(6)]}
     args.injected_noise = inj
 
-    def reward(lat, cap):
+    def reward(lat, cap):                        # BASELINE.json configs[2]: three reward heads, advantage_aggr, weights 1.0
         r = torch.tensor([0.1, 0.4, 0.2, 0.9]) + 0.05 * seed_prompt
-        return r, {"Synthetic": r}
+        heads = {"Synthetic": r, "HeadB": torch.tensor([0.7, 0.1, 0.5, 0.3]) * seed_prompt, "HeadC": r.flip(0) * 2}
+        return sum(heads.values()), heads
 
     res = TG.train_one_step(args, dev, m, None, reward, opt, ConstantWithWarmup(opt, 0), iter([batch]), None, 1.0, [1, 2], 0,
-                            {"Synthetic": 1.0})
+                            {"Synthetic": 1.0, "HeadB": 1.0, "HeadC": 1.0})
     torch.cuda.synchronize()
     return res, m
 
@@ -65,5 +66,9 @@ def test_two_rank_step_on_one_gpu():
     assert s0 == s1 and head0 == head1 and mx0 == mx1          # replicas stay in lockstep
     assert res0[0] == pytest.approx(res1[0])                              # logged loss is the rank average
     assert res0[1] == pytest.approx(res1[1]) and res0[1] > 0             # global grad norm of the averaged gradient
-    assert res0[5]["Synthetic"] == pytest.approx(res1[5]["Synthetic"])  # gathered reward mean over both ranks
+    for head in ("Synthetic", "HeadB", "HeadC"):                          # per-head reward means over BOTH ranks' groups
+        assert res0[5][head] == pytest.approx(res1[5][head])
+    r1, r2 = torch.tensor([0.1, 0.4, 0.2, 0.9]) + 0.05, torch.tensor([0.1, 0.4, 0.2, 0.9]) + 0.10
+    assert res0[5]["Synthetic"] == pytest.approx(torch.cat([r1, r2]).mean().item(), rel=1e-6)
+    assert res0[5]["HeadB"] == pytest.approx(torch.cat([torch.tensor([0.7, 0.1, 0.5, 0.3]), 2 * torch.tensor([0.7, 0.1, 0.5, 0.3])]).mean().item(), rel=1e-6)
     assert all(x == x for x in (res0[0], res0[1], res0[2]))
