@@ -206,12 +206,12 @@ def main():
         # MI355X_MICROARCH.md prescribes for gfx950): it cannot be taken inside this process, so the committed summary
         # of the round's PMC run is quoted, per launch of the profiled shape (see profiles/README.md)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_pmc_v6.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_gemm_pmc_v9.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
             traffic = pmc["traffic_bytes_per_launch"]
-            traffic_src = {"file": "profiles/r01_gemm_pmc_v6.json", "shape": pmc["shape"],
+            traffic_src = {"file": "profiles/r01_gemm_pmc_v9.json", "shape": pmc["shape"],
                            "algorithmic_bytes_per_launch": pmc["algorithmic_bytes_per_launch"],
                            "effective_clock_ghz": pmc["effective_clock_ghz"], "mfma_busy_frac": pmc["mfma_busy_frac"]}
         roofline = {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI> (bf16 MFMA 256x256x64 persistent, all epilogues) "
