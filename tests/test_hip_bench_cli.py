@@ -47,3 +47,14 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3          # both ranks' images over the max time
     assert j["cpu_baseline"] is None                                                   # reported at N = 1 only
     assert j["last_step"]["loss"] == j["last_step"]["loss"]
+
+
+def test_bench_fp8_attention_switch_is_labelled():
+    """`--attention fp8` (BASELINE.json configs[4]'s attention path) runs the same step and says so in `dtype`."""
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "tiny_256_T8_W2_G4", "--steps", "1", "--warmup", "1",
+                        "--attention", "fp8", "--no-roofline", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["dtype"] == "bf16+fp8attn" and j["value"] > 0 and j["roofline"] is None and j["cpu_baseline"] is None
+    assert j["last_step"]["loss"] == j["last_step"]["loss"]
