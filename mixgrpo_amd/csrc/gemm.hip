@@ -642,8 +642,9 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   // tiles that share `band` A panels and 32 / band W panels.  The activation operand streams from HBM, the weights sit
   // in the Infinity Cache: narrow outputs (<= 16 tile columns) take band 1 -- a round is then whole tile rows, every A
   // panel is fetched once (N = 3072, K = 15360: 1308 -> 1371 TFLOP/s against band 8) -- wider ones band 4 (4 x 8 rounds:
-  // +0.7-1 % against 8 x 4; band 1 would put 32 W panels in a round: -3-4 %).
-  const int band = tiles_n <= 16 ? 1 : 4;
+  // +0.7-1 % against 8 x 4; band 1 would put 32 W panels in a round: -3-4 %).  Few tile ROWS (the wgrad shapes with 3072
+  // output rows): the mirror case, one band of all rows, every W panel once (+1 %).
+  const int band = tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4);
   // tile list of this workgroup: the XCD (blockIdx & 7) owns a contiguous range of the banded tile order and its
   // workgroups take every (gridDim/8)-th tile of it
   const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;

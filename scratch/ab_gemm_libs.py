@@ -26,6 +26,8 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 shapes = [(36864, 9216, 3072, 0), (36864, 12288, 3072, 1), (36864, 3072, 15360, 2), (32768, 3072, 3072, 2)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
 for (M, N, K, epi) in shapes:
     fn, C_ = setup(M, N, K, epi)
     _lib._lib = old; fn(); torch.cuda.synchronize(); ref = C_.clone()
