@@ -64,3 +64,47 @@ def oracle_flux(cfg, P):
             return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
 
     return OracleFlux()
+
+
+def free_port():
+    """A TCP port the kernel just handed out (bind to port 0): distinct per call, whatever the pytest pid is."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(worker, world, timeout=300, extra=()):
+    """Start `worker(rank, world, port, queue, *extra)` as `world` daemon processes, collect one queue item per rank and
+    ALWAYS reap the children: a rank that fails can neither hang the collection (bounded `get`) nor pytest's exit (daemon
+    processes, terminate() + join() in `finally`).  Returns the items sorted by their first field (the rank)."""
+    import queue as _queue
+
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra), daemon=True) for r in range(world)]
+    try:
+        for p in procs:
+            p.start()
+        out = []
+        for _ in procs:
+            try:
+                out.append(q.get(timeout=timeout))
+            except _queue.Empty:
+                codes = [p.exitcode for p in procs]
+                raise AssertionError(f"a rank produced no result within {timeout} s (exit codes so far: {codes})")
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        return sorted(out, key=lambda t: t[0])
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()

@@ -5,6 +5,7 @@ case runs in seconds) inside a one-rank gloo group: the whole plumbing -- rollou
 loss, clip, optimizer, logging all-reduces -- with a constant reward, whose known answer is exact: all advantages 0, loss 0,
 gradient norm 0, nothing clipped, and AdamW moves the weights by the weight-decay term only."""
 import os
+import tempfile
 from argparse import Namespace
 
 import torch
@@ -22,8 +23,10 @@ class _Sched:
 
 def test_config0_constant_reward_plumbing():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 200)
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    # a file:// store: no TCPStore server outlives this test in the pytest process (the next gloo test binds its own port)
+    store_file = tempfile.NamedTemporaryFile(prefix="mgx_cfg0_store_", delete=False)
+    store_file.close()
+    dist.init_process_group("gloo", init_method=f"file://{store_file.name}", rank=0, world_size=1)
     try:
         a = Namespace(w=512, h=512, t=1, sampling_steps=8, shift=3.0, init_same_noise=True, training_strategy="part",
                       output_dir="/tmp/x", experiment_name="t", reward_model="const", multi_reward_mix="advantage_aggr",
@@ -57,3 +60,4 @@ def test_config0_constant_reward_plumbing():
             assert torch.allclose(p.detach(), b * (1 - lr * wd) ** 2, rtol=1e-6, atol=1e-9)
     finally:
         dist.destroy_process_group()
+        os.unlink(store_file.name)

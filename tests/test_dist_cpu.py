@@ -5,7 +5,8 @@ import os
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from helpers import run_ranks
 
 
 def _worker(rank, world, port, q):
@@ -43,16 +44,7 @@ def _worker(rank, world, port, q):
 
 
 def test_world_size_2_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = dict(run_ranks(_worker, 2, timeout=120))
     for rk in (0, 1):
         o = res[rk]
         assert o["gathered"] == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]

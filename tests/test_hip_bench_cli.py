@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from helpers import free_port
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +38,7 @@ def test_bench_one_gpu_line_has_the_contract_fields():
 
 def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, MGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + os.getpid() % 300
+    port = free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
                         "--workload", "tiny_256_T8_W2_G4", "--steps", "2", "--warmup", "1"],

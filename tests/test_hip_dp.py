@@ -6,7 +6,8 @@ import os
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from helpers import run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -52,16 +53,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_step_on_one_gpu():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    out = run_ranks(_worker, 2, timeout=300)
     (r0, res0, s0, head0, mx0), (r1, res1, s1, head1, mx1) = out
     assert s0 == s1 and head0 == head1 and mx0 == mx1          # replicas stay in lockstep
     assert res0[0] == pytest.approx(res1[0])                              # logged loss is the rank average
