@@ -99,6 +99,12 @@ int mgx_dpm_step_fwd(const float* sample, const uint16_t* v, const float* m1, co
                      float* x_out, float* x0_out, float* logp, double* ws, int B, long n,
                      const mgx_dpm_coeffs* k /*host*/, void* stream);
 
+/* d log_prob / d model_output of a first-order SDE dpm_step whose sample x_t is held fixed: the training replay under
+ * dpm_apply_strategy="all" (train_grpo_flux.py:170-180 calls dpm_step with dpm_state=None; the log-prob's gradient runs
+ * through prev_sample_mean, sampling_utils.py:376-383).  sigma_b: the scalar autograd multiplies by in d(sigma*v)/dv. */
+int mgx_dpm_step_bwd(const float* sample, const uint16_t* v, const float* x_t, const float* g_logp, uint16_t* dv, int B,
+                     long n, const mgx_dpm_coeffs* k /*host, order 1*/, float sigma_b, void* stream);
+
 /* convert_model_output alone (sampling_utils.py:387-396; used at :116 to feed DPMState inside the window) */
 int mgx_x0_pred(const float* sample, const uint16_t* v, float* x0_out, long total, float sigma_x0, void* stream);
 

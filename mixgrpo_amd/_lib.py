@@ -47,6 +47,7 @@ SIGNATURES = {
     "mgx_dance_step_fwd": (_I, [_P] * 8 + [_I, _L, C.POINTER(DanceCoeffs), _I, _P]),
     "mgx_dance_step_bwd": (_I, [_P] * 5 + [_I, _L, C.POINTER(DanceCoeffs), _I, _P]),
     "mgx_dpm_step_fwd": (_I, [_P] * 9 + [_I, _L, C.POINTER(DpmCoeffs), _P]),
+    "mgx_dpm_step_bwd": (_I, [_P] * 5 + [_I, _L, C.POINTER(DpmCoeffs), _F, _P]),
     "mgx_x0_pred": (_I, [_P, _P, _P, _L, _F, _P]),
     "mgx_pack_latents": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mgx_unpack_latents": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -90,6 +91,11 @@ def lib():
             raise MgxError(f"{LIB_PATH} is missing: run `python -m mixgrpo_amd.build` (hipcc, gfx950). "
                            "There is no CPU fallback for the product path.")
         h = C.CDLL(LIB_PATH)
+        h.mgx_version.restype = _I
+        v = h.mgx_version()
+        if v < 0:
+            raise MgxError(f"{LIB_PATH} is a DIAGNOSTIC build (mgx_version() = {v}, -DMGX_DIAGNOSTIC_BUILD): its timing-only "
+                           "switches compute wrong results.  Rebuild with `python -m mixgrpo_amd.build --force`.")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype = res

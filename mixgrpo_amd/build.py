@@ -2,6 +2,12 @@
 
 `python -m mixgrpo_amd.build [--force]`.  hipcc cross-compiles without a GPU; the .so is git-ignored but
 travels to the GPU box with the gpurun snapshot.
+
+The in-tree library is ALWAYS built from the plain sources: no environment variable changes its flags.  Timing-only
+diagnostic builds (`-DMGX_TIMING_ONLY_*`: wrong results by construction, csrc/common.h) are a separate artefact:
+    python -m mixgrpo_amd.build --diagnostic scratch/libmixgrpo_diag.so -DMGX_TIMING_ONLY_NO_EPILOGUE
+adds -DMGX_DIAGNOSTIC_BUILD (mgx_version() < 0, refused by mixgrpo_amd._lib.lib()), compiles into its own object
+directory and may only be written under scratch/.
 """
 import hashlib
 import os
@@ -17,7 +23,7 @@ LIB = os.path.join(CSRC, "libmixgrpo_hip.so")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-variable", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("MGX_BUILD_EXTRA", "").split()
+          "-Wno-unused-variable", "-Wno-unused-result", "-Wno-unused-value"]
 # files whose results must be bit-identical to separately-rounded eager fp32 ops: no FMA contraction
 # (norm.hip: the reference's RoPE / RMSNorm / LayerNorm are separately rounded eager fp32 ops too, and without the flag
 # the two template instances of qk_norm_rope_fwd contract `y0*c0 - y1*s0` differently: the training forward and the
@@ -46,14 +52,25 @@ def _digest(path, flags):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, diagnostic_out=None, diagnostic_flags=()):
+    """Build the in-tree library (default), or -- with `diagnostic_out` -- a diagnostic one under scratch/."""
+    obj_dir, lib_path, extra = OBJ, LIB, []
+    if diagnostic_out is not None:
+        lib_path = os.path.abspath(diagnostic_out)
+        scratch = os.path.abspath(os.path.join(HERE, "..", "scratch"))
+        if os.path.commonpath([lib_path, scratch]) != scratch:
+            raise RuntimeError(f"diagnostic libraries may only be written under {scratch}")
+        extra = ["-DMGX_DIAGNOSTIC_BUILD"] + list(diagnostic_flags)
+        obj_dir = os.path.join(OBJ, "diag_" + hashlib.sha256(" ".join(extra).encode()).hexdigest()[:12])
+    elif diagnostic_flags:
+        raise RuntimeError("extra compile flags are only accepted for a diagnostic build (diagnostic_out=...)")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in _sources():
-        flags = COMMON + PER_FILE.get(src, [])
+        flags = COMMON + extra + PER_FILE.get(src, [])
         path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         stamp = obj + ".sha"
         dig = _digest(path, flags)
         objs.append(obj)
@@ -77,15 +94,21 @@ def build(force=False, verbose=True):
             for s in ex.map(run, jobs):
                 if verbose:
                     print(f"[mixgrpo_amd.build] compiled {s}")
-    if jobs or force or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if jobs or force or not os.path.exists(lib_path):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
-            print(f"[mixgrpo_amd.build] linked {LIB}")
-    return LIB
+            print(f"[mixgrpo_amd.build] linked {lib_path}")
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    argv = sys.argv[1:]
+    if "--diagnostic" in argv:
+        i = argv.index("--diagnostic")
+        build(force="--force" in argv, diagnostic_out=argv[i + 1],
+              diagnostic_flags=[a for a in argv[i + 2:] if a.startswith("-D") or a.startswith("-f")])
+    else:
+        build(force="--force" in argv)

@@ -35,7 +35,6 @@ def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, 
     from safetensors.torch import save_file
     os.makedirs(save_dir, exist_ok=True)
     sd = optimizer.state_dict()
-    save_file({"m": sd["m"].detach().cpu(), "v": sd["v"].detach().cpu()}, os.path.join(save_dir, "optimizer.safetensors"))
     state = {"global_step": int(global_step), "optimizer_step": int(sd["step"]), "lr": float(sd["lr"]),
              "base_lr": float(optimizer.base_lr)}
     if lr_scheduler is not None:
@@ -44,8 +43,22 @@ def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, 
     if grpo_states is not None:
         state["grpo_states"] = dataclasses.asdict(grpo_states)
         state["grpo_states"]["init_timestep"] = int(grpo_states.init_timestep)
-    with open(os.path.join(save_dir, "trainer_state.json"), "w") as f:
-        json.dump(state, f, indent=2)
+    # serialise the host state FIRST (a value JSON cannot take must not leave a half-written directory behind), write both
+    # files under temporary names and rename them; trainer_state.json goes last: its presence marks a complete resume state
+    text = json.dumps(state, indent=2, default=_json_scalar)
+    tmp_t, tmp_j = os.path.join(save_dir, "optimizer.safetensors.tmp"), os.path.join(save_dir, "trainer_state.json.tmp")
+    save_file({"m": sd["m"].detach().cpu(), "v": sd["v"].detach().cpu()}, tmp_t)
+    with open(tmp_j, "w") as f:
+        f.write(text)
+    os.replace(tmp_t, os.path.join(save_dir, "optimizer.safetensors"))
+    os.replace(tmp_j, os.path.join(save_dir, "trainer_state.json"))
+
+
+def _json_scalar(x):
+    """numpy scalars (the exp_decay budget is a numpy float, window indices may be numpy ints) as python numbers."""
+    if hasattr(x, "item"):
+        return x.item()
+    raise TypeError(f"{type(x).__name__} is not JSON serialisable")
 
 
 def load_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None):

@@ -5,6 +5,16 @@
 
 #include <cstdio>
 
+// Timing-only diagnostic switches (-DMGX_TIMING_ONLY_*, -DMGX_GEMM_COMPILER_WAITS) compile kernels whose RESULTS ARE WRONG
+// (they price one part of a kernel by removing it).  They exist only together with -DMGX_DIAGNOSTIC_BUILD, which makes
+// mgx_version() negative: mixgrpo_amd/_lib.py refuses such a library, and mixgrpo_amd/build.py writes it to scratch/ only.
+#if (defined(MGX_TIMING_ONLY_NO_EPI_STORES) || defined(MGX_TIMING_ONLY_NO_EPILOGUE) || defined(MGX_TIMING_ONLY_NO_DMA) ||   \
+     defined(MGX_TIMING_ONLY_NO_FRAG_READS) || defined(MGX_TIMING_ONLY_MFMA32) || defined(MGX_TIMING_ONLY_NO_KTILE_SYNC) || \
+     defined(MGX_TIMING_ONLY_NO_VMCNT) || defined(MGX_TIMING_ONLY_NO_BARRIER) || defined(MGX_GEMM_COMPILER_WAITS)) &&       \
+    !defined(MGX_DIAGNOSTIC_BUILD)
+#error "MGX_TIMING_ONLY_* / MGX_GEMM_COMPILER_WAITS need -DMGX_DIAGNOSTIC_BUILD (python -m mixgrpo_amd.build --diagnostic ...)"
+#endif
+
 typedef __bf16 bf16_t;
 typedef uint16_t bf16_raw;  // storage view used on the C ABI
 

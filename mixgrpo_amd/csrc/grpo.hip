@@ -73,20 +73,25 @@ __global__ void global_adv_kernel(const float* __restrict__ r, const float* __re
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (r[i] - mean_s) / std_s;
 }
 
+// torch.clamp / torch.maximum propagate NaN (fminf / fmaxf return the other operand): a NaN advantage (use_group=False with
+// one gathered reward: unbiased std of one element) or a NaN log-prob must reach the loss as NaN, as in the reference
+__device__ __forceinline__ float clamp_nan(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? (a + b) : fmaxf(a, b); }
+
 __global__ void grpo_loss_kernel(const float* __restrict__ nlp, const float* __restrict__ olp,
                                  const float* __restrict__ adv, int B, float clip_range, float adv_clip_max,
                                  float kl_coeff, float denom, float* __restrict__ loss, float* __restrict__ policy,
                                  float* __restrict__ kl, float* __restrict__ clip_frac, float* __restrict__ g_logp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float a = fminf(fmaxf(adv[b], -adv_clip_max), adv_clip_max);
+  const float a = clamp_nan(adv[b], -adv_clip_max, adv_clip_max);
   const float diff = nlp[b] - olp[b];
   const float ratio = expf(diff);
   const float lo = 1.0f - clip_range, hi = 1.0f + clip_range;
-  const float rc = fminf(fmaxf(ratio, lo), hi);
+  const float rc = clamp_nan(ratio, lo, hi);
   const float unclipped = -a * ratio;
   const float clipped = -a * rc;
-  const float pol = fmaxf(unclipped, clipped) / denom;
+  const float pol = max_nan(unclipped, clipped) / denom;
   const float klv = 0.5f * (diff * diff) / denom;
   policy[b] = pol;
   kl[b] = klv;

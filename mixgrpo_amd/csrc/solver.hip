@@ -271,6 +271,31 @@ dpm_fwd_kernel(const float* __restrict__ s, const bf16_raw* __restrict__ v, cons
   if (threadIdx.x == 0) ws[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
+// d logp / d v of a first-order DPM-Solver(++) SDE step whose sample x_t is held fixed (prev_sample.detach(), reference
+// sampling_utils.py:376-383): logp = mean(-(x_t - mean)^2 / den - ...), mean = cm0 * s + cm1 * x0, x0 = s - bf16(sigma * v).
+// This is the training replay under dpm_apply_strategy="all" (train_grpo_flux.py:170-180: dpm_state=None -> first order).
+__global__ void __launch_bounds__(kThreads)
+dpm_bwd_kernel(const float* __restrict__ s, const bf16_raw* __restrict__ v, const float* __restrict__ xt,
+               const float* __restrict__ g_logp, bf16_raw* __restrict__ dv, long n, mgx_dpm_coeffs k, float sigma_b) {
+  const long base = (long)blockIdx.y * n;
+  const float g = (g_logp[blockIdx.y] / (float)n) / k.den;
+  for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * kVec; i < n; i += (long)gridDim.x * kThreads * kVec) {
+    const long o = base + i;
+    F8 sv = ld_f32x8(s + o), vv = ld_bf16x8(v + o), xv = ld_f32x8(xt + o), out;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      const float m0 = sv.v[j] - rbf(vv.v[j] * k.sigma_x0);
+      const float mean = k.cm[0] * sv.v[j] + k.cm[1] * m0;
+      const float d = xv.v[j] - mean;
+      const float gm = g * (2.f * d);           // d logp / d mean
+      const float gx0 = gm * k.cm[1];           // mean = cm0 * s + cm1 * x0
+      const float gt = rbf(-gx0);               // x0 = s - T, T = sigma * v in bf16: the gradient reaches T rounded
+      out.v[j] = gt * sigma_b;                  // rounded to bf16 by the store
+    }
+    st_bf16x8(dv + o, out);
+  }
+}
+
 __global__ void __launch_bounds__(kThreads)
 x0_pred_kernel(const float* __restrict__ s, const bf16_raw* __restrict__ v, float* __restrict__ out, long total,
                float sigma_x0) {
@@ -388,6 +413,16 @@ extern "C" int mgx_dpm_step_fwd(const float* sample, const uint16_t* v, const fl
   hipStream_t st = (hipStream_t)stream;
   dpm_fwd_kernel<<<dim3(nb, B), kThreads, 0, st>>>(sample, v, m1, m2, noise, x_out, x0_out, ws, n, *k);
   logp_finalize_kernel<<<B, kThreads, 0, st>>>(ws, logp, nb, n);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_dpm_step_bwd(const float* sample, const uint16_t* v, const float* x_t, const float* g_logp, uint16_t* dv,
+                                int B, long n, const mgx_dpm_coeffs* k, float sigma_b, void* stream) {
+  if (int e = check_common(B, n)) return e;
+  MGX_REQUIRE(sample && v && x_t && g_logp && dv && k, "null argument");
+  MGX_REQUIRE(k->order == 1, "the replayed DPM step has no multistep history: first order only");
+  dpm_bwd_kernel<<<dim3(blocks_per_sample(n), B), kThreads, 0, (hipStream_t)stream>>>(sample, v, x_t, g_logp, dv, n, *k, sigma_b);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

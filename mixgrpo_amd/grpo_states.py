@@ -70,7 +70,8 @@ class GRPOTrainingStates:
         if self.sample_strategy not in _STRATEGIES:
             raise ValueError(f"Invalid sample strategy: {self.sample_strategy}")
         if self.sample_strategy == "random":
-            self.cur_timestep = np.random.default_rng(seed).integers(0, self.max_timesteps - self.group_size + 1)
+            # (a python int: the reference keeps numpy's int64 here, which its own range() accepts but JSON does not)
+            self.cur_timestep = int(np.random.default_rng(seed).integers(0, self.max_timesteps - self.group_size + 1))
             return
         self.cur_iter_in_group += 1
         if self.cur_iter_in_group >= self._window_budget():

@@ -21,43 +21,46 @@ import torch
 from torch.utils.data import Dataset
 
 
-class LatentDataset(Dataset):
-    def __init__(self, json_path, num_latent_t, cfg_rate):
-        self.json_path = json_path
-        self.cfg_rate = cfg_rate
-        self.datase_dir_path = os.path.dirname(json_path)
-        self.prompt_embed_dir = os.path.join(self.datase_dir_path, "prompt_embed")
-        self.pooled_prompt_embeds_dir = os.path.join(self.datase_dir_path, "pooled_prompt_embeds")
-        self.text_ids_dir = os.path.join(self.datase_dir_path, "text_ids")
-        with open(self.json_path, "r") as f:
-            self.data_anno = json.load(f)
-        self.num_latent_t = num_latent_t
-        self.lengths = [item["length"] if "length" in item else 1 for item in self.data_anno]
+# prompt.json key -> sub-directory of the cache that holds the file it names (the on-disk schema, see the module docstring)
+_CACHE_FIELDS = (("prompt_embed_path", "prompt_embed"), ("pooled_prompt_embeds_path", "pooled_prompt_embeds"),
+                 ("text_ids", "text_ids"))
 
-    @staticmethod
-    def _load(path):
-        return torch.load(path, map_location="cpu", weights_only=True)
+
+class LatentDataset(Dataset):
+    """`LatentDataset(json_path, num_latent_t, cfg_rate)[i] -> (prompt_embed [512, 4096], pooled [768], text_ids [3],
+    caption)`.  `num_latent_t` is accepted for signature compatibility (video datasets use it; images have one frame)."""
+
+    def __init__(self, json_path, num_latent_t, cfg_rate):
+        root = os.path.dirname(json_path)
+        with open(json_path, "r") as f:
+            self.entries = json.load(f)               # file order is sample order (the sampler indexes into it)
+        self.field_dirs = {key: os.path.join(root, sub) for key, sub in _CACHE_FIELDS}
+        self.cfg_rate = float(cfg_rate)
+        self.num_latent_t = num_latent_t
+        self.lengths = [e.get("length", 1) for e in self.entries]     # what a length-grouped sampler would read
+
+    def _tensor(self, entry, key):
+        # weights_only=True: nothing from a cache file is executed
+        return torch.load(os.path.join(self.field_dirs[key], entry[key]), map_location="cpu", weights_only=True)
 
     def __getitem__(self, idx):
-        item = self.data_anno[idx]
+        entry = self.entries[idx]
         if random.random() < self.cfg_rate:
             # the reference substitutes a zero prompt embedding here and then fails on the undefined pooled / id
             # tensors (latent_flux_rl_datasets.py:56-78): prompt dropout is not usable in its GRPO trainer (the
             # shipped scripts pass cfg 0.0), so it is rejected here instead of returning a half-initialised sample
             raise RuntimeError("cfg_rate > 0 (prompt dropout) is not supported by the GRPO data path")
-        prompt_embed = self._load(os.path.join(self.prompt_embed_dir, item["prompt_embed_path"]))
-        pooled = self._load(os.path.join(self.pooled_prompt_embeds_dir, item["pooled_prompt_embeds_path"]))
-        text_ids = self._load(os.path.join(self.text_ids_dir, item["text_ids"]))
+        prompt_embed, pooled, text_ids = (self._tensor(entry, key) for key, _ in _CACHE_FIELDS)
         if prompt_embed.dim() == 3 and prompt_embed.shape[0] == 1:
             prompt_embed = prompt_embed[0]
         if pooled.dim() == 2 and pooled.shape[0] == 1:
             pooled = pooled[0]
         if text_ids.dim() == 2:                    # [512, 3] rows of zeros -> the single [3] row the trainer repeats
             text_ids = text_ids[0]
-        return prompt_embed, pooled, text_ids, item["caption"]
+        return prompt_embed, pooled, text_ids, entry["caption"]
 
     def __len__(self):
-        return len(self.data_anno)
+        return len(self.entries)
 
 
 def latent_collate_function(batch):

@@ -194,6 +194,34 @@ class _DanceReplayLogp(torch.autograd.Function):
         return dv, None, None, None, None
 
 
+class _DpmSdeLogp(torch.autograd.Function):
+    """First-order SDE dpm_step (no multistep state) -> (x_t, x0, log_prob) with d log_prob / d model_output: the replay of
+    reference train_grpo_flux.py:170-180, whose log-prob differentiates through prev_sample_mean with the drawn sample
+    detached (sampling_utils.py:376-383)."""
+
+    @staticmethod
+    def forward(ctx, model_output, x, noise, k, sigma_b, out):
+        B, n = _flat(x)
+        v = _as(model_output, _BF16)
+        x0 = torch.empty_like(x)
+        logp = torch.empty(B, dtype=_F32, device=v.device)
+        check(lib().mgx_dpm_step_fwd(ptr(x), ptr(v), None, None, ptr(noise), ptr(out), ptr(x0), ptr(logp),
+                                     ptr(logp_workspace(B, n, v.device)), B, n, C.byref(k), stream()))
+        ctx.save_for_backward(v, x, out)
+        ctx.k, ctx.sigma_b = k, sigma_b
+        ctx.mark_non_differentiable(out, x0)
+        return out, x0, logp
+
+    @staticmethod
+    def backward(ctx, g_out, g_x0, g):
+        v, x, xt = ctx.saved_tensors
+        B, n = _flat(x)
+        dv = torch.empty_like(v)
+        check(lib().mgx_dpm_step_bwd(ptr(x), ptr(v), ptr(xt), ptr(_as(g, _F32)), ptr(dv), B, n, C.byref(ctx.k),
+                                     ctx.sigma_b, stream()))
+        return dv, None, None, None, None, None
+
+
 def flow_grpo_step(model_output, latents, eta, sigmas, index, prev_sample, generator=None, determistic=False,
                    noise=None, prev_out=None, want_x0=True, want_mean=True):
     """Flow-GRPO SDE Euler-Maruyama step + Gaussian log-prob (reference sampling_utils.py:157-210).
@@ -362,6 +390,9 @@ def dpm_step(args, model_output, sample, step_index, timesteps, sigmas, dpm_stat
                  else _as(variance_noise.to(dev), _F32))
     k = dpm_coeffs(args.dpm_algorithm_type, args.dpm_solver_type, order, sigmas, step_index, sde_solver)
     out = x_out if x_out is not None else torch.empty_like(x)
+    if sde_solver and not dpm_state and model_output.requires_grad and torch.is_grad_enabled():
+        # training replay under dpm_apply_strategy="all": the log-prob carries a gradient to the model output
+        return _DpmSdeLogp.apply(model_output, x, noise, k, _u(_host(sigmas).to(_F32)[step_index]), out)
     x0 = torch.empty_like(x)
     logp = torch.empty(B, dtype=_F32, device=dev)
     check(lib().mgx_dpm_step_fwd(ptr(x), ptr(v), ptr(m1), ptr(m2), ptr(noise), ptr(out), ptr(x0), ptr(logp),

@@ -87,8 +87,9 @@ def grpo_one_step(args, latents, pre_latents, encoder_hidden_states, pooled_prom
             return SU.flow_grpo_step(pred, latents.to(F32), args.eta, sigma_schedule, i, pre_latents.to(F32),
                                      determistic=False, want_x0=False, want_mean=False)[2]
         return SU.dance_grpo_step(pred, latents.to(F32), args.eta, sigma_schedule, i, pre_latents.to(F32), True, True)[2]
-    # strategy "all" under DPM: the reference draws fresh noise and scores ITS OWN sample (train_grpo_flux.py:170-180)
-    return SU.dpm_step(args, pred.detach(), latents.to(F32), i, sigma_schedule[:-1], sigma_schedule, dpm_state=None,
+    # strategy "all" under DPM (train_grpo_flux.py:170-180): a first-order SDE step from a freshly (default-)seeded
+    # generator; the log-prob scores that step's own sample (detached) and differentiates through its mean
+    return SU.dpm_step(args, pred, latents.to(F32), i, sigma_schedule[:-1], sigma_schedule, dpm_state=None,
                        generator=torch.Generator(device=dev), sde_solver=True)[2]
 
 
@@ -317,9 +318,6 @@ def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, eh
     P = len(pairs)
     use_flow = args.dpm_algorithm_type == "null" or ("dpmsolver" in args.dpm_algorithm_type
                                                      and args.dpm_apply_strategy == "post")
-    if not use_flow:
-        raise NotImplementedError("replay under dpm_apply_strategy='all' scores freshly drawn samples in the reference "
-                                  "(train_grpo_flux.py:170-180) and carries no gradient to the stored transition")
     v = pred.detach()
     new_lp = torch.empty(P, device=dev, dtype=F32)
     dv = torch.empty_like(v)
@@ -332,8 +330,23 @@ def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, eh
             s0 = k
     import ctypes as C
     coeffs = []
+    dpm_noise = dpm_xt = None
+    if not use_flow:
+        # dpm_apply_strategy="all" (train_grpo_flux.py:170-180): every replay call runs a first-order SDE dpm_step from
+        # a freshly default-seeded generator -- the SAME [1, N, C] noise for every (sample, step) pair -- and scores that
+        # step's own sample; the stored next latent is not used.  (`injected_noise["dpm_replay"]`: parity tests only.)
+        inj = getattr(args, "injected_noise", None)
+        one = inj["dpm_replay"].to(dev) if inj and "dpm_replay" in inj else \
+            torch.randn((1,) + tuple(x.shape[1:]), generator=torch.Generator(device=dev), device=dev, dtype=F32)
+        dpm_noise = one.to(F32).expand(P, -1, -1).contiguous()
+        dpm_xt = torch.empty_like(x)
     for lo, hi, t in slices:
-        if args.flow_grpo_sampling:
+        if not use_flow:
+            kf = SU.dpm_coeffs(args.dpm_algorithm_type, args.dpm_solver_type, 1, sig_host, t, True)
+            check(lib().mgx_dpm_step_fwd(ptr(x[lo:hi]), ptr(v[lo:hi]), None, None, ptr(dpm_noise[lo:hi]),
+                                         dpm_xt[lo:hi].data_ptr(), None, new_lp[lo:hi].data_ptr(),
+                                         ptr(SU.logp_workspace(hi - lo, n, dev)), hi - lo, n, C.byref(kf), stream()))
+        elif args.flow_grpo_sampling:
             kf = SU.flow_coeffs(sig_host, t, args.eta)
             check(lib().mgx_flow_step_fwd(ptr(x[lo:hi]), ptr(v[lo:hi]), None, ptr(nxt[lo:hi]), None, None, None,
                                           new_lp[lo:hi].data_ptr(), ptr(SU.logp_workspace(hi - lo, n, dev)), hi - lo, n,
@@ -350,7 +363,11 @@ def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, eh
                               out[3].data_ptr(), out[4].data_ptr(), stream()))
     g_lp = out[4]
     for (lo, hi, t), kf in zip(slices, coeffs):
-        if args.flow_grpo_sampling:
+        if not use_flow:
+            check(lib().mgx_dpm_step_bwd(ptr(x[lo:hi]), ptr(v[lo:hi]), ptr(dpm_xt[lo:hi]), g_lp[lo:hi].data_ptr(),
+                                         dv[lo:hi].data_ptr(), hi - lo, n, C.byref(kf),
+                                         SU._u(SU._host(sig_host).to(F32)[t]), stream()))
+        elif args.flow_grpo_sampling:
             check(lib().mgx_flow_step_bwd(ptr(x[lo:hi]), ptr(v[lo:hi]), ptr(nxt[lo:hi]), g_lp[lo:hi].data_ptr(),
                                           dv[lo:hi].data_ptr(), hi - lo, n, C.byref(kf), stream()))
         else:

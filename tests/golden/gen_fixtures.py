@@ -159,6 +159,17 @@ def gen_solver(su):
     tensors["dpm/nostate/noise"] = noise
     tensors["dpm/nostate/prev"] = prev
     tensors["dpm/nostate/logp"] = lp
+    # ... and its gradient w.r.t. the model output (the reference differentiates through prev_sample_mean, :376-383),
+    # for both algorithm types, with a per-sample upstream gradient
+    for algo in ("dpmsolver++", "dpmsolver"):
+        a = dpm_args(dpm_algorithm_type=algo)
+        vg = v.clone().requires_grad_(True)
+        _, _, lpg = su.dpm_step(a, vg, x, 3, sig[:-1], sig, dpm_state=None, variance_noise=noise, sde_solver=True)
+        up = torch.tensor([0.75, -1.5])
+        (lpg * up).sum().backward()
+        tensors[f"dpm/nostate_grad/{algo}/logp"] = lpg.detach().clone()
+        tensors[f"dpm/nostate_grad/{algo}/upstream"] = up
+        tensors[f"dpm/nostate_grad/{algo}/grad_v"] = vg.grad.clone()
     return tensors, meta
 
 
@@ -187,9 +198,20 @@ def gen_rollout(su):
             det[i] = False
         NOISE_LOG.clear()
         torch.manual_seed(4242)
-        with torch.no_grad():
-            z, lat, all_lat, all_lp = su.run_sample_step(a, z0, range(T), sig, model, ehs, pooled, text_ids, ids,
-                                                         True, det)
+        real_randn_like = torch.randn_like
+
+        def logged_randn_like(t, *aa, **kk):           # dance_grpo_step draws with randn_like, not randn_tensor
+            r = real_randn_like(t, *aa, **kk)
+            NOISE_LOG.append(r.clone())
+            return r
+
+        torch.randn_like = logged_randn_like
+        try:
+            with torch.no_grad():
+                z, lat, all_lat, all_lp = su.run_sample_step(a, z0, range(T), sig, model, ehs, pooled, text_ids, ids,
+                                                             True, det)
+        finally:
+            torch.randn_like = real_randn_like
         tensors[f"{tag}/z"] = z.clone()
         tensors[f"{tag}/latents"] = lat.clone()
         tensors[f"{tag}/all_latents"] = all_lat.clone()
@@ -410,12 +432,92 @@ def gen_trainer(tg):
         eta=0.3, timestep_fraction=0.6)
     run("flash_post", {"HeadA": [0.4, 0.2, 0.3, 0.1]}, {"HeadA": 1.0}, T=12, window=(0, 1),
         dpm_algorithm_type="dpmsolver++", dpm_post_compress_ratio=0.4)
+    # DPM-Solver++ on EVERY step (dpm_apply_strategy="all"): SDE dpm_step inside the window during the rollout, and a
+    # state-less first-order SDE dpm_step in the replay whose log-prob differentiates through its mean (:170-180)
+    run("dpm_all", {"HeadA": [0.4, 0.3, 0.1, 0.2]}, {"HeadA": 1.0}, dpm_algorithm_type="dpmsolver++", dpm_apply_strategy="all",
+        dpm_solver_order=2, dpm_solver_type="midpoint", kl_coeff=0.01)
     dist.destroy_process_group()
     return tensors, meta
 
 
+# --------------------------------------------------------------------------- MMDiT structural witnesses
+def gen_mmdit_witness():
+    """The FLUX MMDiT itself is third-party (diffusers, absent).  What /root/reference DOES hold is sibling code built
+    from the same formulas (witness table): RoPE tables and rotation, the sinusoidal embedding, RMSNorm,
+    modulate / gate.  Their outputs at FLUX shapes (axes 16/56/56, head_dim 128, 256-wide sinusoid) pin the corresponding
+    pieces of oracle/mmdit.py; the block wiring stays unpinned."""
+    pe = load_ref("ref_posemb_layers", "fastvideo/models/hunyuan/modules/posemb_layers.py")
+    nl = load_ref("ref_norm_layers", "fastvideo/models/hunyuan/modules/norm_layers.py")
+    mn = load_ref("ref_mochi_norm", "fastvideo/models/mochi_hf/norm.py")
+    ml = load_ref("ref_modulate_layers", "fastvideo/models/hunyuan/modules/modulate_layers.py")
+    # embed_layers.py does `from ..utils.helpers import to_2tuple` at import: give it its own package context
+    pkg = types.ModuleType("ref_hy")
+    pkg.__path__ = [os.path.join(REF, "fastvideo/models/hunyuan")]
+    sys.modules["ref_hy"] = pkg
+    for sub in ("modules", "utils"):
+        m = types.ModuleType(f"ref_hy.{sub}")
+        m.__path__ = [os.path.join(REF, "fastvideo/models/hunyuan", sub)]
+        sys.modules[f"ref_hy.{sub}"] = m
+    load_ref("ref_hy.utils.helpers", "fastvideo/models/hunyuan/utils/helpers.py")
+    el = load_ref("ref_hy.modules.embed_layers", "fastvideo/models/hunyuan/modules/embed_layers.py")
+
+    t, meta = {}, {}
+    g = torch.Generator().manual_seed(20251004)
+    # --- RoPE tables: per axis, positions 0..63 (FLUX ids: text rows all 0, image rows (0, row, col), 64 x 64 grid)
+    axes = (16, 56, 56)
+    pos = torch.arange(64).float()
+    for a, dim in enumerate(axes):
+        cos, sin = pe.get_1d_rotary_pos_embed(dim, pos, theta=10000.0, use_real=True)
+        t[f"rope/axis{a}/cos"], t[f"rope/axis{a}/sin"] = cos.contiguous(), sin.contiguous()
+    meta["rope"] = {"axes_dims": list(axes), "positions": 64, "theta": 10000.0,
+                    "note": "witness computes the frequencies in float32 (posemb_layers.py:303-306); diffusers' FluxPosEmbed "
+                            "(and oracle/mmdit.py) in float64 on CPU/CUDA"}
+    # --- rotation: interleaved pairs, fp32 arithmetic, cast back to the input dtype
+    S_, H_, D_ = 64, 2, 128
+    ids = torch.stack([torch.zeros(S_), torch.arange(S_) % 64, (torch.arange(S_) * 7) % 64], dim=1)
+    cos = torch.cat([t[f"rope/axis{a}/cos"][ids[:, a].long()] for a in range(3)], dim=1)
+    sin = torch.cat([t[f"rope/axis{a}/sin"][ids[:, a].long()] for a in range(3)], dim=1)
+    t["rot/ids"], t["rot/cos"], t["rot/sin"] = ids, cos, sin
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        xq = torch.randn(1, S_, H_, D_, generator=g).to(dt)
+        xk = torch.randn(1, S_, H_, D_, generator=g).to(dt)
+        oq, ok = pe.apply_rotary_emb(xq, xk, (cos, sin), head_first=False)
+        t[f"rot/{tag}/xq"], t[f"rot/{tag}/xk"], t[f"rot/{tag}/oq"], t[f"rot/{tag}/ok"] = xq, xk, oq.contiguous(), ok.contiguous()
+    # --- sinusoidal timestep embedding [cos | sin], 128 frequencies
+    ts = torch.tensor([1000.0, 986.0, 952.0, 971.0, 111.0, 0.0, 3500.0, 3488.0, 123.5])
+    t["sincos/t"], t["sincos/out"] = ts, el.timestep_embedding(ts, 256)
+    # --- RMSNorm over head_dim 128 with a learned weight (q / k norms)
+    w = 1.0 + 0.1 * torch.randn(128, generator=g)
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = (2.0 * torch.randn(2, 3, 16, 128, generator=g)).to(dt)
+        hy = nl.RMSNorm(128, eps=1e-6)
+        mo = mn.MochiRMSNorm(128, eps=1e-6)
+        with torch.no_grad():
+            hy.weight.copy_(w)
+            mo.weight.copy_(w)
+            t[f"rms/{tag}/x"], t[f"rms/{tag}/hunyuan"], t[f"rms/{tag}/mochi"] = x, hy(x).contiguous(), mo(x).contiguous()
+    t["rms/w"] = w
+    meta["rms"] = {"eps": 1e-6, "note": "hunyuan RMSNorm rounds the normalised tensor to the input dtype BEFORE the weight "
+                                        "multiply (norm_layers.py:56-59); MochiRMSNorm multiplies in fp32 and casts at the end "
+                                        "(mochi_hf/norm.py:52-63), like diffusers' RMSNorm with an fp32 weight"}
+    # --- modulate / gate as AdaLN-Zero uses them under autocast: fp32 LayerNorm output, bf16 shift / scale / gate
+    x = torch.randn(2, 6, 3072, generator=g)
+    ln = torch.nn.functional.layer_norm(x, (3072,), None, None, 1e-6)
+    shift = (0.2 * torch.randn(2, 3072, generator=g)).to(torch.bfloat16)
+    scale = (0.2 * torch.randn(2, 3072, generator=g)).to(torch.bfloat16)
+    gate = (0.5 * torch.randn(2, 3072, generator=g)).to(torch.bfloat16)
+    y = torch.randn(2, 6, 3072, generator=g).to(torch.bfloat16)
+    res = torch.randn(2, 6, 3072, generator=g).to(torch.bfloat16)
+    t["mod/x"], t["mod/shift"], t["mod/scale"] = x, shift, scale
+    t["mod/out"] = ml.modulate(ln, shift=shift, scale=scale).contiguous()
+    t["gate/y"], t["gate/gate"], t["gate/res"] = y, gate, res
+    t["gate/out"] = (res + ml.apply_gate(y, gate=gate)).contiguous()
+    meta["dtypes"] = {k: str(v.dtype) for k, v in t.items()}
+    return t, meta
+
+
 def main():
-    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer"]
+    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer", "mmdit"]
     install_light_stub()
     su = load_ref("ref_sampling_utils", "fastvideo/utils/sampling_utils.py")
     if "solver" in which:
@@ -432,6 +534,11 @@ def main():
         gs = load_ref("ref_grpo_states", "fastvideo/utils/grpo_states.py")
         json.dump(gen_windows(gs), open(os.path.join(HERE, "windows.json"), "w"))
         print("windows ok")
+    if "mmdit" in which:
+        t, m = gen_mmdit_witness()
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(HERE, "mmdit_witness.safetensors"))
+        json.dump(m, open(os.path.join(HERE, "mmdit_witness.json"), "w"), indent=1)
+        print("mmdit witness:", len(t), "tensors")
     if "trainer" in which:
         tg = load_trainer()
         t, m = gen_trainer(tg)

@@ -34,6 +34,8 @@ def test_bench_one_gpu_line_has_the_contract_fields():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["achieved"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert j["lib_version"] >= 100                              # a release build of the library (diagnostic builds: < 0)
+    assert j["config"]["rollout_solver_steps"] == 8 and j["mfma_frac_train_step_executed"] <= j["mfma_frac_train_step"]
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -49,6 +51,24 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3          # both ranks' images over the max time
     assert j["cpu_baseline"] is None                                                   # reported at N = 1 only
     assert j["last_step"]["loss"] == j["last_step"]["loss"]
+
+
+def test_bench_launches_its_own_ranks():
+    """The driver's launcher-less form `python3 bench.py --gpus N ...` for N > 1 (no WORLD_SIZE): the parent starts the N
+    ranks as child processes before touching the GPU, relays rank 0's JSON line and exits with the launcher's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny_256_T8_W2_G4", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 8
+    assert j["roofline"]["achieved"] > 0                       # the profiled step is the (only) warm-up step
+    # a failing launch is reported through the parent's exit code (here: 3 ranks asked, --gpus 2 given to each)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                        "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--workload",
+                        "tiny_256_T8_W2_G4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
 
 
 def test_bench_fp8_attention_switch_is_labelled():

@@ -50,6 +50,20 @@ CASES = [
       "Pick": [((5 * i + 3) % 12) / 6 for i in range(12)]}, {"HPS": 1.0, "IR": 1.0, "Pick": 1.0}, [0, 1, 2, 3]),
     ("sliding50_g16", dict(sampling_steps=50, num_generations=16, gradient_accumulation_steps=3),
      {"A": [((11 * i + 2) % 16) / 16 for i in range(16)]}, {"A": 1.0}, [10, 11, 12, 13]),
+    # reference branches with pinned oracle fixtures (tests/golden/trainer.json: balance, dance_all) on the HIP path:
+    # advantage_rerange_strategy (reward_model/utils.py:18-48 via train_grpo_flux.py:524-532; python `random`, seeded on
+    # both sides; a zero advantage drops its sample) and training_strategy="all" (:503-522,552: every step SDE, DanceGRPO
+    # solver, per-sample torch.randperm of the T-1 kept transitions, the first int((T-1)*timestep_fraction) of them trained)
+    ("balance", dict(num_generations=6, advantage_rerange_strategy="balance"),
+     {"A": [0.9, 0.2, 0.35, 0.4, 0.1, 0.77]}, {"A": 1.0}, [2, 3]),
+    ("balance_drops_zero_adv", dict(num_generations=5, advantage_rerange_strategy="balance", gradient_accumulation_steps=2),
+     {"A": [0.25, 0.5, 0.75, 0.5, 0.5]}, {"A": 1.0}, [2, 3]),
+    ("rerange_random", dict(num_generations=6, advantage_rerange_strategy="random", gradient_accumulation_steps=3),
+     {"A": [0.9, 0.2, 0.35, 0.4, 0.1, 0.77]}, {"A": 1.0}, [1, 2]),
+    ("dance_all", dict(training_strategy="all", flow_grpo_sampling=False, timestep_fraction=0.6, kl_coeff=0.01),
+     {"A": [0.1, 0.2, 0.3, 0.4]}, {"A": 1.0}, [2, 3]),
+    ("flow_all_frozen", dict(training_strategy="all", frozen_init_timesteps=3, num_generations=5),
+     {"A": [0.3, 0.1, 0.8, 0.4, 0.6]}, {"A": 1.0}, [0, 1]),
 ]
 
 
@@ -81,10 +95,14 @@ def test_train_one_step_vs_oracle(tag, kw, rewards, weights, window):
     oo = torch.optim.AdamW(mo.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     po = torch.optim.AdamW(mp.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     tro, trp = {}, {}
+    torch.manual_seed(714)                       # host RNG consumers on the path: torch.randperm (strategy "all") ...
+    random.seed(714)                             # ... and python `random` (balance_pos_neg); same stream on both sides
     ro = OT.train_one_step(a, mo, oo, _Sched(), (ehs, pooled, text_ids, ["p"]), o_reward, weights, window, 1.0, trace=tro,
                            injected=inj)
     ap = copy.copy(a)
     ap.injected_noise = inj
+    torch.manual_seed(714)
+    random.seed(714)
     rp = TG.train_one_step(ap, torch.device("cuda"), mp, None, p_reward, po, _Sched(),
                            iter([(ehs, pooled, text_ids, ["p"])]), None, 1.0, window, 0, weights, trace=trp)
     assert torch.allclose(trp["advantages"].cpu(), tro["advantages"], rtol=1e-5, atol=1e-6)
@@ -137,3 +155,57 @@ def test_skip_dead_backward_changes_nothing_but_work():
         outs.append((res, m.a.item(), calls["bwd"]))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     assert outs[1][2] < outs[0][2]                      # fewer backward passes really ran
+
+
+def _nogroup_case(B, rewards):
+    """use_group=False (reference train_grpo_flux.py:494-499): a batch of B prompts, one sample each, advantages
+    normalised by the mean / unbiased std of the GATHERED rewards -> `mgx_global_advantage`."""
+    from mixgrpo_amd import train_grpo_flux as TG
+    a = base_args(use_group=False, multi_reward_mix="reward_aggr", num_generations=1, gradient_accumulation_steps=2)
+    T = a.sampling_steps
+    lh, lw = a.h // 8, a.w // 8
+    N = (lh // 2) * (lw // 2)
+    g = torch.Generator().manual_seed(9)
+    inj = {"x_T": torch.randn(1, 16, lh, lw, generator=g).bfloat16(),
+           "steps": [torch.randn(B, N, 64, generator=g).bfloat16() for _ in range(T)]}
+    ehs = (0.1 * torch.randn(B, 8, 32, generator=g)).bfloat16()
+    pooled = torch.randn(B, 16, generator=g).bfloat16()
+    text_ids = torch.zeros(B, 3)
+    caps = [f"p{i}" for i in range(B)]
+    mo, mp = ElementwiseToy(), ElementwiseToy().cuda()
+    oo = torch.optim.AdamW(mo.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+    po = torch.optim.AdamW(mp.parameters(), lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+    tro, trp = {}, {}
+    ro = OT.train_one_step(a, mo, oo, _Sched(), (ehs, pooled, text_ids, caps),
+                           lambda i, lat: ([rewards[i]], {"A": [rewards[i]]}), {"A": 1.0}, [2, 3], 1.0, trace=tro, injected=inj)
+    ap = copy.copy(a)
+    ap.injected_noise = inj
+    rp = TG.train_one_step(ap, torch.device("cuda"), mp, None,
+                           lambda lat, cap: ([rewards[i] for i in range(lat.shape[0])], {"A": [rewards[i] for i in range(lat.shape[0])]}),
+                           po, _Sched(), iter([(ehs, pooled, text_ids, caps)]), None, 1.0, [2, 3], 0, {"A": 1.0}, trace=trp)
+    return ro, rp, tro, trp, mo, mp
+
+
+def test_nogroup_global_advantage_vs_oracle():
+    rewards = [0.3, 0.1, 0.8, 0.4]
+    ro, rp, tro, trp, mo, mp = _nogroup_case(4, rewards)
+    r = torch.tensor(rewards)
+    assert torch.allclose(tro["advantages"], (r - r.mean()) / (r.std() + 1e-8))          # the reference formula (:498)
+    assert torch.allclose(trp["advantages"].cpu(), tro["advantages"], rtol=1e-5, atol=1e-6)
+    fin = torch.isfinite(tro["log_probs"])
+    assert torch.allclose(trp["log_probs"].cpu()[fin], tro["log_probs"][fin], rtol=1e-5, atol=1e-6)
+    for k in (0, 2, 3, 4):
+        assert rp[k] == pytest.approx(ro[k], rel=2e-4, abs=3e-6), (k, rp, ro)
+    assert rp[1] == pytest.approx(ro[1], rel=2e-3, abs=1e-7)
+    assert rp[5] == pytest.approx(ro[5], rel=1e-6)
+    assert mp.a.item() == pytest.approx(mo.a.item(), rel=1e-4)
+
+
+def test_nogroup_single_sample_is_nan_like_the_reference():
+    """The pinned `nogroup` fixture (tests/golden/trainer.json): one prompt, one sample, world size 1 -> the unbiased std of
+    one reward is NaN, and so are the advantage, the loss and the gradient norm in the reference; the HIP path must not
+    turn that into a number."""
+    ro, rp, tro, trp, _, _ = _nogroup_case(1, [0.3])
+    assert torch.isnan(tro["advantages"]).all() and torch.isnan(trp["advantages"]).all()
+    assert rp[0] != rp[0] and ro[0] != ro[0]                       # NaN loss on both sides
+    assert rp[5] == pytest.approx(ro[5], rel=1e-6)

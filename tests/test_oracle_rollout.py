@@ -23,10 +23,8 @@ def eq(a, b):
 @pytest.mark.parametrize("case", M_["cases"], ids=lambda c: c["tag"])
 def test_rollout(case, inject):
     a = Namespace(**case["args"])
-    if inject and not (a.flow_grpo_sampling or a.dpm_apply_strategy == "all"):
-        pytest.skip("randn_like draws are not captured by the generator's noise log")
-    if inject and "dpmsolver" in a.dpm_algorithm_type and a.dpm_apply_strategy == "all":
-        pass
+    # (inject: the noise the reference drew -- randn_tensor AND the DanceGRPO step's randn_like -- is replayed from the
+    # fixture instead of being re-drawn from the seeded generator: pins the rollout independently of the RNG stream)
     T = case["T"]
     sig = S.sd3_time_shift(a.shift, torch.linspace(1, 0, T + 1))
     det = [True] * T

@@ -86,3 +86,19 @@ def test_dpm_without_state():
                               variance_noise=T_["dpm/nostate/noise"], sde_solver=True)
     eq(prev, T_["dpm/nostate/prev"])
     eq(lp, T_["dpm/nostate/logp"])
+
+
+@pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
+def test_dpm_without_state_gradient(algo):
+    """The replay under dpm_apply_strategy="all" (reference train_grpo_flux.py:170-180): the state-less first-order SDE
+    dpm_step's log-prob differentiates through prev_sample_mean (sampling_utils.py:376-383).  Fixture: the reference's own
+    autograd gradient w.r.t. the bf16 model output."""
+    a = Namespace(dpm_algorithm_type=algo, dpm_solver_order=2, dpm_solver_type="midpoint")
+    sig = T_["sigma/shift3.0_T8"]
+    v = T_["in/v"].clone().requires_grad_(True)
+    _, _, lp = O.dpm_step(a, v, T_["in/x"], 3, sig[:-1], sig, dpm_state=None, variance_noise=T_["dpm/nostate/noise"],
+                          sde_solver=True)
+    eq(lp.detach(), T_[f"dpm/nostate_grad/{algo}/logp"])
+    (lp * T_[f"dpm/nostate_grad/{algo}/upstream"]).sum().backward()
+    assert v.grad.abs().max() > 0
+    eq(v.grad, T_[f"dpm/nostate_grad/{algo}/grad_v"])
