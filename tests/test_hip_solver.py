@@ -253,3 +253,30 @@ def test_shared_prefix_rollout_is_bit_identical(window, kw):
                                            shared_rows=shared))
     for x, y in zip(outs[0], outs[1]):
         assert torch.equal(torch.nan_to_num(x.contiguous(), nan=7.0), torch.nan_to_num(y.contiguous(), nan=7.0))
+
+
+@pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
+def test_dpm_replay_gradient(algo):
+    """`mgx_dpm_step_bwd`: d log_prob / d model_output of the state-less first-order SDE dpm_step, the training replay under
+    dpm_apply_strategy="all" (reference train_grpo_flux.py:170-180, sampling_utils.py:376-383) -- against the oracle's
+    autograd on the same host (elementwise: bit-exact) and the reference's own gradient vector."""
+    from mixgrpo_amd import sampling_utils as SU
+    a = Namespace(dpm_algorithm_type=algo, dpm_solver_order=2, dpm_solver_type="midpoint")
+    sig = T_["sigma/shift3.0_T8"]
+    x, noise, up = T_["in/x"], T_["dpm/nostate/noise"], T_[f"dpm/nostate_grad/{algo}/upstream"]
+    vo = T_["in/v"].clone().requires_grad_(True)
+    po, _, lo = O.dpm_step(a, vo, x, 3, sig[:-1], sig, dpm_state=None, variance_noise=noise, sde_solver=True)
+    (lo * up).sum().backward()
+    vp = T_["in/v"].cuda().requires_grad_(True)
+    pp, _, lp = SU.dpm_step(a, vp, dev(x), 3, sig[:-1], sig, dpm_state=None, variance_noise=dev(noise), sde_solver=True)
+    assert lp.requires_grad
+    (lp * up.cuda()).sum().backward()
+    eq(pp, po.detach())
+    close_lp(lp, lo.detach())
+    assert vp.grad.dtype == torch.bfloat16 and vp.grad.abs().max() > 0
+    eq(vp.grad, vo.grad)
+    assert_same(vp.grad, T_[f"dpm/nostate_grad/{algo}/grad_v"], exact=False, rtol=1e-2, atol=1e-9)   # bf16 gradient: 1 ulp of bf16
+    # without grad (the rollout) the same call still returns plain tensors
+    with torch.no_grad():
+        assert not SU.dpm_step(a, vp, dev(x), 3, sig[:-1], sig, dpm_state=None, variance_noise=dev(noise),
+                               sde_solver=True)[2].requires_grad

@@ -64,6 +64,12 @@ CASES = [
      {"A": [0.1, 0.2, 0.3, 0.4]}, {"A": 1.0}, [2, 3]),
     ("flow_all_frozen", dict(training_strategy="all", frozen_init_timesteps=3, num_generations=5),
      {"A": [0.3, 0.1, 0.8, 0.4, 0.6]}, {"A": 1.0}, [0, 1]),
+    # DPM-Solver++ on every step (dpm_apply_strategy="all"; pinned oracle fixture `dpm_all`): SDE dpm_step in the window
+    # during the rollout, and a state-less first-order SDE dpm_step in the replay, whose log-prob carries a gradient through
+    # its mean (train_grpo_flux.py:170-180).  The replay's noise comes from a freshly default-seeded generator in the
+    # reference -- the same tensor for every pair; injected here (CPU and GPU generators differ)
+    ("dpm_all", dict(dpm_algorithm_type="dpmsolver++", dpm_apply_strategy="all", kl_coeff=0.01),
+     {"A": [0.4, 0.3, 0.1, 0.2]}, {"A": 1.0}, [2, 3]),
 ]
 
 
@@ -77,6 +83,11 @@ def test_train_one_step_vs_oracle(tag, kw, rewards, weights, window):
     g = torch.Generator().manual_seed(5)
     inj = {"x_T": torch.randn(1, 16, lh, lw, generator=g).bfloat16(),
            "steps": [torch.randn(G, N, 64, generator=g).bfloat16() for _ in range(T)]}
+    dpm_all = a.dpm_apply_strategy == "all" and "dpmsolver" in a.dpm_algorithm_type
+    if dpm_all or not a.flow_grpo_sampling:
+        inj["steps"] = [n.float() for n in inj["steps"]]    # dpm_step / dance_grpo_step draw fp32 noise (sampling_utils.py:319,237)
+    if dpm_all:
+        inj["dpm_replay"] = torch.randn((1, N, 64), generator=torch.Generator())   # what the oracle's fresh generator draws
     ehs = (0.1 * torch.randn(1, 8, 32, generator=g)).bfloat16()
     pooled = torch.randn(1, 16, generator=g).bfloat16()
     text_ids = torch.zeros(1, 3)
