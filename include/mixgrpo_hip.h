@@ -221,6 +221,9 @@ int mgx_ew_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, long n, int o
 /* diffusers Timesteps(256, flip_sin_to_cos=True, shift 0): out[b] = bf16([cos(t_b f) | sin(t_b f)]) */
 int mgx_sincos_embed(const float* t, uint16_t* out, int Bn, void* stream);
 int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
+/* y = scale * float(x) (n % 8 == 0).  With mgx_cast_f32_bf16: the bf16 gradient buckets of the data-parallel all-reduce
+ * (the reference's FSDP reduce-scatters its gradients per wrapped block, fastvideo/utils/fsdp_util.py:56-66) */
+int mgx_cast_bf16_f32(const uint16_t* x, float* y, long n, float scale, void* stream);
 /* Backward of x + gate*y: dy = bf16(gate[b]*dout), dgate[b,:] = sum_rows dout*y (bf16) */
 long mgx_gate_bwd_workspace(long batches, long rows_per_batch, int D);
 int mgx_gate_bwd(const uint16_t* dout, long ldd, long d_bstride, const uint16_t* y, long ldy, const uint16_t* gate,

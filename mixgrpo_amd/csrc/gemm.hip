@@ -370,7 +370,16 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
 // per-row `if (in range) { load; use; store }` makes hipcc emit branch + load + s_waitcnt vmcnt(0) per row, i.e.
 // serial HBM round trips (vmcnt counts stores too, so each wait also drains the previous row's store): that form
 // cost ~20 us of an 80 us K=3072 tile.
+// (Variant kept for A/B, -DMGX_EPI_LAYOUT16: the lane's four accumulator tiles as 16 CONSECUTIVE features.  Default: tiles
+// t = 0, 1 are features fq*8 .. fq*8+7 and tiles t = 2, 3 the same + 32, so that ONE 16-byte store instruction of the wave
+// writes 64 contiguous bytes per token row -- half a 128-byte line -- instead of four 16-byte pieces 32 bytes apart.)
+#ifdef MGX_EPI_LAYOUT16
 __device__ __forceinline__ int wperm(int p) { return ((p & 15) >> 2) * 16 + (p >> 4) * 4 + (p & 3); }
+__device__ __forceinline__ int lane_feat(int fq, int t) { return fq * 16 + t * 4; }
+#else
+__device__ __forceinline__ int wperm(int p) { return (p >> 5) * 32 + ((p & 15) >> 2) * 8 + ((p >> 4) & 1) * 4 + (p & 3); }
+__device__ __forceinline__ int lane_feat(int fq, int t) { return (t >> 1) * 32 + fq * 8 + (t & 1) * 4; }
+#endif
 
 __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
   v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
@@ -390,7 +399,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
                                                  long n0) {
   constexpr int MT = 8;
   const int wm = wid >> 2, wn = wid & 3, fr = lane & 15, fq = lane >> 4;
-  const long n = n0 + wn * 64 + fq * 16;          // this lane's 16 consecutive output features
+  const long nw = n0 + wn * 64;                   // the wave's 64 output features; tile t of this lane: nw + lane_feat(fq, t)
   // N % 4 == 0 always; on the 16-byte paths N % 8 == 0: the two 8-feature halves are in range independently
   const long mrow0 = m0 + wm * 128 + fr;          // rows mrow0 + 16 j
 
@@ -401,8 +410,8 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
     long ncol[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      nok[t] = n + t * 4 < g.N;
-      ncol[t] = nok[t] ? n + t * 4 : 0;
+      nok[t] = nw + lane_feat(fq, t) < g.N;
+      ncol[t] = nok[t] ? nw + lane_feat(fq, t) : 0;
     }
 #pragma unroll
     for (int jb = 0; jb < MT; jb += 2) {          // two rows (8 float4) of read-modify-write loads in flight
@@ -447,7 +456,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
       const long bidx = (uint32_t)m / (uint32_t)g.c.rpb;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const long nn = n + t * 4;
+        const long nn = nw + lane_feat(fq, t);
         if (nn >= g.N) continue;
         float v[4] = {acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]};
         if (g.bias) {
@@ -500,8 +509,9 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
   const char* cbase = reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + nu) * 2;
   const char* abase = reinterpret_cast<const char*>(g.aux) + (mu * g.ldaux + nu) * 2;
   const int rmax = (int)(g.M - 1 - mu < 127 ? g.M - 1 - mu : 127);      // last valid row of the block
-  const bool nok0 = nu + fq * 16 < g.N, nok1 = nu + fq * 16 + 8 < g.N;   // N % 8 == 0 on this path
-  const uint32_t c0 = nok0 ? fq * 32 : 0, c1 = nok1 ? fq * 32 + 16 : 0;  // byte offsets of the two 8-feature halves
+  const int f0 = lane_feat(fq, 0), f1 = lane_feat(fq, 2);                // first feature of the lane's two 8-feature halves
+  const bool nok0 = nu + f0 < g.N, nok1 = nu + f1 < g.N;                 // N % 8 == 0 on this path
+  const uint32_t c0 = nok0 ? f0 * 2 : 0, c1 = nok1 ? f1 * 2 : 0;         // their byte offsets
   const uint32_t ldc2 = (uint32_t)(g.c.ld * 2), lda2 = (uint32_t)(g.ldaux * 2);
   auto rowclamp = [&](int j) { const int r = fr + 16 * j; return (uint32_t)(r < rmax ? r : rmax); };
 

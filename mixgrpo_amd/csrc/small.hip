@@ -117,6 +117,18 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_raw* __re
   }
 }
 
+// y = scale * float(x): the all-reduced bf16 gradient bucket back into the flat fp32 gradient buffer (dist_utils.GradReducer)
+__global__ void cast_bf16_f32_kernel(const bf16_raw* __restrict__ x, float* __restrict__ y, long n, float scale) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + i);
+    float4 a, b;
+    a.x = bf2f(u.x & 0xffff) * scale; a.y = bf2f(u.x >> 16) * scale; a.z = bf2f(u.y & 0xffff) * scale; a.w = bf2f(u.y >> 16) * scale;
+    b.x = bf2f(u.z & 0xffff) * scale; b.y = bf2f(u.z >> 16) * scale; b.z = bf2f(u.w & 0xffff) * scale; b.w = bf2f(u.w >> 16) * scale;
+    *reinterpret_cast<float4*>(y + i) = a;
+    *reinterpret_cast<float4*>(y + i + 4) = b;
+  }
+}
+
 // gate-residual backward helpers on [rows, D] row-batched streams:
 //   dgate[b, c] = sum_rows dout[m, c] * y[m, c]   (y = pre-gate branch output), dy[m, c] = bf16(gate[b, c] * dout[m, c])
 // Block = 32 rows of one batch x 256 columns... each thread owns 1 column pair across the block's rows.
@@ -202,6 +214,16 @@ extern "C" int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stre
   int nb = cdiv(n, 1024);
   if (nb > 4096) nb = 4096;
   cast_f32_bf16_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(x, y, n);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_cast_bf16_f32(const uint16_t* x, float* y, long n, float scale, void* stream) {
+  MGX_REQUIRE(x && y && n > 0 && n % 8 == 0, "bad argument");
+  MGX_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "operands must be 16-byte aligned");
+  int nb = cdiv(n, 2048);
+  if (nb > 4096) nb = 4096;
+  cast_bf16_f32_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(x, y, n, scale);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -138,6 +138,22 @@ class ParamStore:
             return buf[off:off + rows_total]
         return buf[off:off + rows_total * shape[1]].view(rows_total, shape[1])
 
+    def block_ranges(self):
+        """{block prefix: (lo, hi)} element ranges of the flat buffers, in layout order (transformer blocks; everything
+        before / after them under "head" / "tail").  Contiguous and 64-aligned: the buckets of the DP gradient reduction."""
+        names = list(self.index)
+        key = lambda n: ".".join(n.split(".")[:2]) if n.startswith(("transformer_blocks.", "single_transformer_blocks.")) \
+            else ("head" if self.index[n][0] < self.index["norm_out.linear.weight"][0] else "tail")
+        out, cur, lo = {}, None, 0
+        for n in names:
+            k = key(n)
+            if k != cur:
+                if cur is not None:
+                    out[cur] = (lo, self.index[n][0])
+                cur, lo = k, self.index[n][0]
+        out[cur] = (lo, self.numel)
+        return out
+
     def sync_bf16(self):
         self.w16.copy_(self.w32)
 

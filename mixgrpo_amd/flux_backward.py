@@ -212,6 +212,10 @@ def _backward(model, w, tr, sv, dout):
                         de[:, d:2 * d], de[:, 0:d], d)
     _skinny_bwd(model, tr, de, st_, "norm_out.linear.weight", "norm_out.linear.bias", 2 * d, d, dst)
 
+    # data-parallel overlap (dist_utils.GradReducer): set by the trainer for the LAST micro-batch before an optimizer step;
+    # called with a block's prefix once every gradient of that block is final
+    grad_ready = getattr(model, "_grad_ready", None) or (lambda prefix: None)
+    grad_ready("tail")
     nblk = cfg.num_layers + cfg.num_single_layers
     # ---------------- single blocks (reverse)
     for i in reversed(range(cfg.num_single_layers)):
@@ -254,6 +258,7 @@ def _backward(model, w, tr, sv, dout):
         _dgrad(model, tr, dbr, 7 * d, d, f"{p}.attn.to_q.weight", Rows.of(tr.dnrm), rows=True)
         ops.ln_modulate_bwd(tr.dnrm, x_in, m[:, d:2 * d], 3 * d, dXr, True, dmod[:, 0:d], dmod[:, d:2 * d], d)
         _skinny_bwd(model, tr, dmod, st_, f"{p}.norm.linear.weight", f"{p}.norm.linear.bias", 3 * d, d, dst)
+        grad_ready(p)
 
     # ---------------- double blocks (reverse)
     streams = (("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", N, L),
@@ -313,6 +318,7 @@ def _backward(model, w, tr, sv, dout):
             ops.ln_modulate_bwd(dn, srows(tr.block_in[i], name, d), m[:, d:2 * d], 6 * d, dXs, True, dm[:, 0:d],
                                 dm[:, d:2 * d], d)
             _skinny_bwd(model, tr, dm, st_, f"{p}.{norm}.linear.weight", f"{p}.{norm}.linear.bias", 6 * d, d, dst)
+        grad_ready(p)
 
     # ---------------- embedders (inputs need no gradient)
     _wgrad(model, tr, Rows.of(sv["in16"]), cfg.in_channels, srows(tr.dX, "img", d), d, "x_embedder.weight",

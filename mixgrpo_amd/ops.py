@@ -142,6 +142,11 @@ def cast_bf16(x, y):
     check(lib().mgx_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()))
 
 
+def cast_f32(x, y, scale=1.0):
+    """y (fp32) = scale * x (bf16)."""
+    check(lib().mgx_cast_bf16_f32(ptr(x), ptr(y), x.numel(), float(scale), stream()))
+
+
 def gate_bwd(dout: Rows, y, gate, gate_ld, dy, dgate, batches, rows_per_batch, D):
     ws = scratch("gate_bwd", lib().mgx_gate_bwd_workspace(batches, rows_per_batch, D), F32, y.device)
     check(lib().mgx_gate_bwd(ptr(dout.t), dout.ld, dout.bstride, ptr(y), D, gate.data_ptr(), gate_ld, ptr(dy), D,

@@ -24,7 +24,7 @@ import torch.distributed as dist
 from . import ops
 from . import sampling_utils as SU
 from ._lib import check, lib, ptr, stream
-from .dist_utils import allreduce_mean_vec_, allreduce_sum_, gather_tensor, is_dist, main_print, rank, world_size
+from .dist_utils import GradReducer, allreduce_mean_vec_, gather_tensor, is_dist, main_print, rank, world_size
 from .latents import pack_latents, prepare_latent_image_ids, unpack_latents  # noqa: F401  (re-exported surface)
 
 F32, BF16 = torch.float32, torch.bfloat16
@@ -179,13 +179,24 @@ def compute_advantages(args, rewards, reward_weights, gathered):
     return adv
 
 
+def _grad_reducer(transformer):
+    """The bucketed SUM all-reduce over the model's flat gradient buffer (dist_utils.GradReducer; mode / overlap from
+    `transformer.dp_grad_dtype` / `transformer.dp_overlap`, else the MGX_DP_GRAD_DTYPE / MGX_DP_OVERLAP environment)."""
+    g = transformer.store.ensure_grad()
+    r = getattr(transformer, "_mgx_grad_reducer", None)
+    if r is None or r.flat.data_ptr() != g.data_ptr():
+        r = GradReducer(g, mode=getattr(transformer, "dp_grad_dtype", None), overlap=getattr(transformer, "dp_overlap", None))
+        transformer._mgx_grad_reducer = r
+    return r
+
+
 def _fused_step(transformer, optimizer, max_grad_norm):
     """clip_grad_norm_ + optimizer.step() (reference :606-607).  With the flat store and FusedAdamW: DP gradient
     all-reduce (sum) -> one sum-of-squares pass -> AdamW with the clip factor inside.  Returns the device grad norm."""
     ws = world_size()
     store = getattr(transformer, "store", None)
     if store is not None and hasattr(optimizer, "grad_sqnorm"):
-        allreduce_sum_(store.ensure_grad())
+        _grad_reducer(transformer).finish()          # (buckets launched during the backward, if any, + the rest)
         nsq = optimizer.grad_sqnorm()
         optimizer.step(max_grad_norm=max_grad_norm, grad_scale=1.0 / ws)
         return nsq.sqrt().squeeze(0) / ws
@@ -280,9 +291,23 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
             pairs.sort(key=lambda p: p[1])                     # step-major: one coefficient set per contiguous slice
             for m0 in range(0, len(pairs), mb or len(pairs)):
                 part = pairs[m0:m0 + (mb or len(pairs))]
-                _replay_backward(args, transformer, part, lat_steps, all_log_probs, adv, encoder_hidden_states,
-                                 pooled_prompt_embeds, txt_ids, img_ids, guidance, timestep_value, sig_host, denom, log,
-                                 trace, need_grad=not dead)
+                # data-parallel overlap: during the LAST micro-batch before an optimizer step a block's gradients are
+                # final as soon as its backward is done -> its buckets go out while the rest of the backward runs
+                last_mb = m0 + (mb or len(pairs)) >= len(pairs) and len(chunk) == accum
+                hooked = False
+                if last_mb and is_dist() and world_size() > 1 and getattr(transformer, "store", None) is not None:
+                    red = _grad_reducer(transformer)
+                    if red.overlap:
+                        ranges = transformer.store.block_ranges()
+                        transformer._grad_ready = lambda prefix, r_=red, rg_=ranges: r_.reduce_range(*rg_[prefix], async_op=True)
+                        hooked = True
+                try:
+                    _replay_backward(args, transformer, part, lat_steps, all_log_probs, adv, encoder_hidden_states,
+                                     pooled_prompt_embeds, txt_ids, img_ids, guidance, timestep_value, sig_host, denom, log,
+                                     trace, need_grad=not dead)
+                finally:
+                    if hooked:
+                        transformer._grad_ready = None
         if len(chunk) == accum:                                # optimizer step every `accum` samples (:605-609)
             grad_norm = _fused_step(transformer, optimizer, max_grad_norm)
             if trace is not None:

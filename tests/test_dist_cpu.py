@@ -26,6 +26,16 @@ def _worker(rank, world, port, q):
     works = DU.allreduce_sum_(torch.ones(10), async_op=True)
     for w in works:
         w.wait()
+    # GradReducer (fp32 mode runs on host tensors too): two block ranges launched asynchronously "during the backward", the
+    # gaps (head of the buffer, a middle range, the tail) picked up by finish(); every element summed exactly once
+    flat = torch.arange(64 * 40, dtype=torch.float32) * (rank + 1)
+    red = DU.GradReducer(flat, mode="fp32", bucket_elems=64 * 3, overlap=True)
+    red.reduce_range(64 * 30, 64 * 36, async_op=True)
+    red.reduce_range(64 * 10, 64 * 20, async_op=True)
+    red.finish()
+    out["reducer_ok"] = bool(torch.equal(flat, torch.arange(64 * 40, dtype=torch.float32) * 3)) and not red.pending
+    red.finish()                                     # nothing launched: reduces the whole buffer once more
+    out["reducer_again"] = bool(torch.equal(flat, torch.arange(64 * 40, dtype=torch.float32) * 6))
     v = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
     out["mean_vec"] = DU.allreduce_mean_vec_(v).tolist()
     out["rank_world"] = (DU.rank(), DU.world_size(), DU.is_dist())
@@ -51,6 +61,7 @@ def test_world_size_2_gloo():
         assert o["gsum_head"] == [4.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 4.0]
         assert o["mean_vec"] == [1.5, 3.0, 4.5, 6.0]
         assert o["rank_world"] == (rk, 2, True)
+        assert o["reducer_ok"] and o["reducer_again"]
     # reference: full-batch gradient of the mean of the two per-shard losses
     torch.manual_seed(0)
     w0 = torch.randn(5, requires_grad=True)

@@ -15,13 +15,14 @@ CFG = dict(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attent
            pooled_projection_dim=32)
 
 
-def _one_step(rank, world, seed_prompt):
+def _one_step(rank, world, seed_prompt, mode="bf16", overlap=False):
     from mixgrpo_amd import train_grpo_flux as TG
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
     from mixgrpo_amd.optim import ConstantWithWarmup, FusedAdamW
     dev = torch.device("cuda", 0)
     m = FluxTransformer2DModel(FluxConfig(**CFG), device=dev).init_synthetic(seed=5, std=0.05, bias_std=0.02)
     opt = FusedAdamW(m, lr=1e-3)
+    m.dp_grad_dtype, m.dp_overlap = mode, overlap      # dist_utils.GradReducer: bucket dtype, launch during the backward
     args = TG.default_args(h=48, w=64, sampling_steps=6, num_generations=4, gradient_accumulation_steps=2)
     g = torch.Generator().manual_seed(seed_prompt)
     batch = ((0.1 * torch.randn(1, 16, 64, generator=g)).bfloat16().to(dev), torch.randn(1, 32, generator=g).bfloat16().to(dev),
@@ -41,19 +42,44 @@ def _one_step(rank, world, seed_prompt):
     return res, m
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="bf16", overlap=False, save_to=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res, m = _one_step(rank, world, seed_prompt=rank + 1)
+    res, m = _one_step(rank, world, seed_prompt=rank + 1, mode=mode, overlap=overlap)
     w = m.store.w32.detach().cpu()
+    if save_to and rank == 0:
+        torch.save(w, save_to)
+    red = m._mgx_grad_reducer
+    assert red.mode == mode and red.overlap == overlap and not red.pending and not red.launched
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res, w.double().sum().item(), w[:4096].tolist(), w.abs().max().item()))   # plain python objects only
 
 
-def test_two_rank_step_on_one_gpu():
-    out = run_ranks(_worker, 2, timeout=300)
+@pytest.mark.parametrize("mode,overlap", [("bf16", False), ("fp32", False), ("bf16", True), ("fp32", True)])
+def test_two_rank_step_on_one_gpu(mode, overlap, tmp_path):
+    out = run_ranks(_worker, 2, timeout=300, extra=(mode, overlap, str(tmp_path / "w.pt")))
+    _check_two_rank_results(out)
+    # the reduced gradient is the SAME tensor whether its buckets went out during the backward or after it, and the bf16
+    # buckets change the update only within bf16 rounding of the summed gradient: compare against the fp32, non-overlapped
+    # step (the reference's FSDP reduces in fp32)
+    ref = tmp_path / "ref.pt"
+    out_ref = run_ranks(_worker, 2, timeout=300, extra=("fp32", False, str(ref)))
+    w, w_ref = torch.load(tmp_path / "w.pt"), torch.load(ref)
+    if mode == "fp32":
+        assert torch.equal(w, w_ref)                                   # overlap does not change a single bit
+        assert out[0][1][1] == out_ref[0][1][1]
+    else:
+        lr = 1e-3
+        # first AdamW step: update = -lr * g / (|g| + eps'): bf16 rounding of g moves a weight by a fraction of lr at most,
+        # except where the summed gradient is ~0 (sign flips: up to 2 lr)
+        assert (w - w_ref).abs().max().item() <= 2.5 * lr
+        assert (w - w_ref).abs().mean().item() < 0.02 * lr
+        assert out[0][1][1] == pytest.approx(out_ref[0][1][1], rel=1e-2)          # global gradient norm
+
+
+def _check_two_rank_results(out):
     (r0, res0, s0, head0, mx0), (r1, res1, s1, head1, mx1) = out
     assert s0 == s1 and head0 == head1 and mx0 == mx1          # replicas stay in lockstep
     assert res0[0] == pytest.approx(res1[0])                              # logged loss is the rank average
