@@ -58,20 +58,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 // NW waves per workgroup (QB = 32*NW queries).  NW = 4 puts two independent workgroups on a CU (64 KiB LDS each): their
 // barriers are unrelated, so one workgroup's softmax VALU phase runs under the other's MFMA phase instead of the two
 // waves of a SIMD marching in lockstep.
-//
-// STAG (staggered halves): the two waves of a SIMD (w, w + NW/2) run the same three phases per tile -- S^T MFMAs, softmax
-// VALU, P V MFMAs -- and, released by the same barrier, run them in LOCKSTEP: both compete for the matrix pipe, then both
-// for the VALU while the pipe idles.  With STAG the second half of the waves ("late") DEFERS each tile's P V product to the
-// start of the next iteration (P stays in registers across the barrier): early = [S(t) | softmax(t) | PV(t)], late =
-// [PV(t-1) | S(t) | softmax(t)], so a SIMD always has one wave's MFMAs beside the other wave's softmax.  Still ONE barrier
-// per tile; the V tile lives one iteration longer: LDS = 2 K slots + 3 V slots.  Results are bit-identical (same
-// operations per query row in the same order).
-template <int NW, bool DEFER, bool STAG = false>
+template <int NW, bool DEFER>
 __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   constexpr int QB = QW * NW;
   constexpr int NCH = 1024 / (NW * 64);   // 16-byte chunks per thread per operand tile
-  // LDS: !STAG: [2][K tile | Vt tile];  STAG: K slots at 0, 16K; V slots at 32K, 48K, 64K
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | Vt tile]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
@@ -131,12 +122,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
     char* vb_ptr = kb_ptr + K_TILE_BYTES;                                                           \
     STORE1(0, sk0, sv0) STORE1(1, sk1, sv1) STORE1(2, sk2, sv2) STORE1(3, sk3, sv3)                 \
   } while (0)
-#define STORE_KV2(kslot, vslot)                                                                     \
-  do {                                                                                              \
-    char* kb_ptr = smem + (kslot) * K_TILE_BYTES;                                                   \
-    char* vb_ptr = smem + 2 * K_TILE_BYTES + (vslot) * V_TILE_BYTES;                                \
-    STORE1(0, sk0, sv0) STORE1(1, sk1, sv1) STORE1(2, sk2, sv2) STORE1(3, sk3, sv3)                 \
-  } while (0)
 
   f32x16 o[4];   // O^T tiles: d in [32*dt, 32*dt+32), column = query r
 #pragma unroll
@@ -146,131 +131,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   float m_run = -INFINITY;   // running max of raw scores (shared by both half-waves)
   float l_run = 0.f;         // this lane's partial row sum
 
-  if constexpr (STAG) {
-    // ---------------------------------------------------------------- staggered halves (see the kernel's header comment)
-    LOAD_KV(0);
-    STORE_KV2(0, 0);
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(qf[ks]));
-    uint32_t pb[2][8];                              // P^T of the tile whose P V product is pending (late) / current (early)
-    // S^T of tile t from K slot `kslot` + online softmax -> pb, m_run, l_run, rescaled o
-    auto s_softmax = [&](int t, int kslot, auto mask_tag) __attribute__((always_inline)) {
-      constexpr bool MASK = decltype(mask_tag)::value;
-      const char* ks_ = smem + kslot * K_TILE_BYTES;
-      f32x16 s[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-      {
-        s16x8 kf[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const s16x8*>(ks_ + k_off(r, ks * 2 + h));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[0], 0, 0, 0);
-          kf[ks] = *reinterpret_cast<const s16x8*>(ks_ + k_off(32 + r, ks * 2 + h));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (MASK) {
-        const int key_base = t * KB;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (key >= g.S) s[kb][i] = -INFINITY;
-          }
-      }
-      float mx = s[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      constexpr float DEFER_LOG2 = 6.0f;
-      bool rescale = true;
-      if (DEFER) rescale = __builtin_amdgcn_ballot_w64((mx - m_run) * g.scale_log2e > DEFER_LOG2) != 0;
-      float alpha = 1.0f;
-      if (rescale) {                                 // (late waves: the pending P V product has been issued before this point)
-        const float m_new = fmaxf(m_run, mx);
-        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * g.scale_log2e);
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-      }
-      const float mc = m_run * g.scale_log2e;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(s[kb][i] * g.scale_log2e - mc);
-          const float p1 = __builtin_amdgcn_exp2f(s[kb][i + 1] * g.scale_log2e - mc);
-          psum += p0 + p1;
-          pb[kb][i >> 1] = pack_bf16(p0, p1);
-        }
-      l_run = l_run * alpha + psum;
-    };
-    // O^T += Vt P^T with the V tile in slot `vslot` and P^T in pb
-    auto pv = [&](int vslot) __attribute__((always_inline)) {
-      const char* vs_ = smem + 2 * K_TILE_BYTES + vslot * V_TILE_BYTES;
-      s16x8 vfr[2][4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) vfr[0][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, h));
-#pragma unroll
-      for (int idx = 0; idx < 4; ++idx) {
-        const int kb = idx >> 1, s2 = idx & 1;
-        const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
-        const s16x8 pf = __builtin_bit_cast(s16x8, u);
-        if (idx + 1 < 4) {
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            vfr[(idx + 1) & 1][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, (idx + 1) * 2 + h));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[idx & 1][dt], pf, o[dt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    const int nfull = g.S / KB;
-    const bool late = __builtin_amdgcn_readfirstlane(wid) >= NW / 2;     // wave-uniform, provably (scalar branch)
-    int vcur = 0, vprev = 2, vnext = 1;             // V slots of tiles t, t - 1, t + 1 (rotating mod 3)
-    // one iteration; the ragged last tile (compile-time MASK) runs outside the loops, like in the classic path: a runtime
-    // "last tile" test inside the loop is if-converted into ~200 selects per tile
-    auto iter = [&](int t, auto late_tag, auto mask_tag) __attribute__((always_inline)) {
-      constexpr bool LATE = decltype(late_tag)::value;
-      if (t + 1 < ntiles) LOAD_KV(t + 1);
-      if (LATE) {
-        if (t > 0) pv(vprev);                       // the P V product of tile t - 1, beside the partner wave's S^T / softmax
-        s_softmax(t, t & 1, mask_tag);
-      } else {
-        s_softmax(t, t & 1, mask_tag);
-        pv(vcur);
-      }
-      if (t + 1 < ntiles) STORE_KV2((t + 1) & 1, vnext);
-      __syncthreads();
-      const int x = vprev; vprev = vcur; vcur = vnext; vnext = x;
-    };
-    if (!late) {
-      for (int t = 0; t < nfull; ++t) iter(t, std::false_type{}, std::false_type{});
-      if (nfull < ntiles) iter(nfull, std::false_type{}, std::true_type{});
-    } else {
-      for (int t = 0; t < nfull; ++t) iter(t, std::true_type{}, std::false_type{});
-      if (nfull < ntiles) iter(nfull, std::true_type{}, std::true_type{});
-      pv(vprev);                                    // last tile's product (its slot is never rewritten)
-    }
-  } else {
   LOAD_KV(0);
   STORE_KV(0);
   __syncthreads();
@@ -391,7 +251,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   const int nfull = g.S / KB;
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntiles) tile(nfull, std::true_type{});
-  }
 
   // ---- finalize: row sum across the two half-waves, normalise, store O[q][h*128 + d]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -430,18 +289,9 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   g.scale_log2e = scale * 1.4426950408889634f;
   static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 8;
   static const int defer = getenv("MGX_ATTN_DEFER") ? atoi(getenv("MGX_ATTN_DEFER")) : 1;
-  static const int stag = getenv("MGX_ATTN_STAG") ? atoi(getenv("MGX_ATTN_STAG")) : 1;
   const int lds = 2 * (K_TILE_BYTES + V_TILE_BYTES);
   hipStream_t st = (hipStream_t)stream;
-  if (nw == 8 && defer && stag) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * K_TILE_BYTES + 3 * V_TILE_BYTES);
-      attr = true;
-    }
-    attn_fwd_kernel<8, true, true><<<cdiv(S, 256) * H * B, 512, 2 * K_TILE_BYTES + 3 * V_TILE_BYTES, st>>>(g);
-  } else if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
+  if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (nw == 8) attn_fwd_kernel<8, false><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (defer) attn_fwd_kernel<4, true><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
   else attn_fwd_kernel<4, false><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);

@@ -697,8 +697,22 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #ifdef MGX_TIMING_ONLY_NO_DMA             /* diagnostic build (wrong results): no operand staging in the K-loop */
 #define PGLDS_ONE(base, off, off_lds) asm volatile("" :: "v"(off))
 #else
-#define PGLDS_ONE(base, off, off_lds) \
-  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
+#ifndef MGX_GEMM_A_AUX
+#define MGX_GEMM_A_AUX 0      /* cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2, sc1 = 16); A/B-tested, see DESIGN.md */
+#endif
+#ifndef MGX_GEMM_W_AUX
+#define MGX_GEMM_W_AUX 0
+#endif
+#define PGLDS_AUX(base, off, off_lds, aux) \
+  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, aux)
+#define PGLDS_ONE(base, off, off_lds) PGLDS_AUX(base, off, off_lds, 0)
+#endif
+#ifdef MGX_TIMING_ONLY_NO_DMA
+#define PGLDS_A(base, off, off_lds) PGLDS_ONE(base, off, off_lds)
+#define PGLDS_W(base, off, off_lds) PGLDS_ONE(base, off, off_lds)
+#else
+#define PGLDS_A(base, off, off_lds) PGLDS_AUX(base, off, off_lds, MGX_GEMM_A_AUX)
+#define PGLDS_W(base, off, off_lds) PGLDS_AUX(base, off, off_lds, MGX_GEMM_W_AUX)
 #endif
 #define DMA_A(AO, kt_, slot_)                                                                                  \
   do {                                                                                                        \
@@ -761,12 +775,19 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #else
 #define MMA_GROUP(ks, gq)                                                                                  \
   do {                                                                                                     \
+    PRIO(1);                                                                                               \
     _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
       _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
+    PRIO(0);                                                                                               \
   } while (0)
 #endif
 #define PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef MGX_GEMM_SETPRIO       /* A/B variant: raised wave priority around every 8-MFMA group */
+#define PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PRIO(x) do {} while (0)
+#endif
 
   TILE_COORDS(t_lin, m0, n0);
   TILE_OFFS(m0, n0, ao, wo);
@@ -819,8 +840,8 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       const uint32_t sa_u = lds0 + aslot * TB, sw_u = lds0 + WBASE + wslot * TB;
       const uint32_t a_ad[2] = {sa_u + a_ro[0], sa_u + a_ro[1]}, w_ad[2] = {sw_u + w_ro[0], sw_u + w_ro[1]};
       // the four W pieces first thing (they must land within this iteration: every cycle of lead counts, +2-7 %)
-      PGLDS_ONE(wb_, cw[0], lw_); PGLDS_ONE(wb_, cw[1], lw_ + RS * 128);
-      PGLDS_ONE(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_ONE(wb_, cw[3], lw_ + 3 * RS * 128);
+      PGLDS_W(wb_, cw[0], lw_); PGLDS_W(wb_, cw[1], lw_ + RS * 128);
+      PGLDS_W(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_W(wb_, cw[3], lw_ + 3 * RS * 128);
       PIN();
       // head reads r1..r10, the two the first MFMA needs in front
       RD_W(0, 0); RD_A(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3); RD_A(0, 1);
@@ -848,13 +869,13 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       PIN();
       RD_A(1, 2); RD_A(1, 3);                                           // r19, r20
       // the four A pieces (two K-tiles of lead) in pairs behind MFMA groups (all eight at the top: 6-9 % slower)
-      PGLDS_ONE(ab_, ca[0], la_); PGLDS_ONE(ab_, ca[1], la_ + RS * 128);
+      PGLDS_A(ab_, ca[0], la_); PGLDS_A(ab_, ca[1], la_ + RS * 128);
       PIN();
       WAIT2(8, fa[0][6], fa[0][7]);                                     // r11, r12
       MMA_GROUP(0, 3);
       PIN();
       RD_A(1, 4); RD_A(1, 5);                                           // r21, r22
-      PGLDS_ONE(ab_, ca[2], la_ + 2 * RS * 128); PGLDS_ONE(ab_, ca[3], la_ + 3 * RS * 128);
+      PGLDS_A(ab_, ca[2], la_ + 2 * RS * 128); PGLDS_A(ab_, ca[3], la_ + 3 * RS * 128);
       PIN();
       WAIT6(4, fw[1][0], fw[1][1], fw[1][2], fw[1][3], fa[1][0], fa[1][1]);   // r13..r18
       MMA_GROUP(1, 0);
@@ -923,6 +944,10 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #undef MMA1
 #undef MMA_GROUP
 #undef PIN
+#undef PRIO
+#undef PGLDS_A
+#undef PGLDS_W
+#undef PGLDS_AUX
 }
 
 template <int EPI>

@@ -7,7 +7,8 @@ from mixgrpo_amd.ops import Rows
 new = _lib.lib()
 old = C.CDLL(os.path.join("scratch", "libmixgrpo_old.so"))
 for name, (res, args) in _lib.SIGNATURES.items():
-    fn = getattr(old, name); fn.restype = res; fn.argtypes = args
+    if hasattr(old, name):               # (an older build may lack entry points added since)
+        fn = getattr(old, name); fn.restype = res; fn.argtypes = args
 torch.manual_seed(0)
 dev = "cuda"
 def setup(M, N, K, epi):
