@@ -180,8 +180,8 @@ int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const fl
 long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch);
 int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
                          const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dqkv,
-                         float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp, int rows_per_batch, int s0,
-                         void* stream);
+                         long ld_dqkv /* elements between rows of dqkv, >= ld */, float* gwq, float* gwk, float* ws, int B,
+                         int H, int S, int Sp, int rows_per_batch, int s0, void* stream);
 
 /* O = softmax(scale * Q K^T) V, non-causal, head_dim 128 (F.scaled_dot_product_attention under autocast):
  * Q,K [B,H,S,128], Vt [B,H,128,Sp] (Sp = S rounded up to 64, padding finite), O [B,S,ldo] at column h*128,

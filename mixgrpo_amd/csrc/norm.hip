@@ -301,6 +301,7 @@ struct QkBwdArgs {
   const bf16_raw* dK;
   const bf16_raw* dV;
   bf16_raw* dqkv;
+  long ldo;        // elements between consecutive rows of dqkv (>= 3*H*128: e.g. the [M, 7d] staging matrix of the single blocks)
   float* part;     // [nblocks][2][128]
   int H, S, Sp, rows_per_batch, s0;
 };
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
     const long row = (long)b * a.rows_per_batch + t;
     const int s = a.s0 + t;
     const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
-    bf16_raw* obase = a.dqkv + row * a.ld + hh * HD + 2 * lane;
+    bf16_raw* obase = a.dqkv + row * a.ldo + hh * HD + 2 * lane;
     const float c0 = a.cos[(long)s * HD + 2 * lane], c1 = a.cos[(long)s * HD + 2 * lane + 1];
     const float s0 = a.sin[(long)s * HD + 2 * lane], s1 = a.sin[(long)s * HD + 2 * lane + 1];
     const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
@@ -449,12 +450,13 @@ extern "C" long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch)
 
 extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
                                     const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
-                                    uint16_t* dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp,
-                                    int rows_per_batch, int s0, void* stream) {
+                                    uint16_t* dqkv, long ld_dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S,
+                                    int Sp, int rows_per_batch, int s0, void* stream) {
   MGX_REQUIRE(qkv && wq && wk && cos && sin && dQ && dK && dV && dqkv && gwq && gwk && ws, "null argument");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
+  MGX_REQUIRE(ld_dqkv >= ld && ld_dqkv % 2 == 0, "dqkv rows must hold [dq | dk | dv] and keep 4-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ws, H, S, Sp, rows_per_batch, s0};
+  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ld_dqkv, ws, H, S, Sp, rows_per_batch, s0};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
   qk_bwd_finish_kernel<<<16, 256, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);

@@ -398,10 +398,11 @@ class FluxTransformer2DModel(torch.nn.Module):
             return Rows(t, w.B * w.L, width, w.L, w.S * width)
         return Rows(t[0, w.L:], w.B * w.N, width, w.N, w.S * width)
 
-    def _double_block(self, i, w, st, cos, sin, save=None, mods_in=None, keep=None, replay=False):
+    def _double_block(self, i, w, st, cos, sin, save=None, mods_in=None, keep=None, replay=False, x_in=None):
         """`save`: keep the block's intermediates for the backward walk (recompute pass).  `keep`: per-block buffers
         {O, lse, y_attn, y_ff, x_mid} written by the training forward; with `replay` the recompute pass reads them
-        back instead of re-running attention and the two output projections (to_out / ff.net.2)."""
+        back instead of re-running attention and the two output projections (to_out / ff.net.2), and reads the block's
+        input from `x_in` (the saved block input: the residual stream is not written in this mode, so no copy of it)."""
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"transformer_blocks.{i}"
         B = w.B
@@ -418,7 +419,7 @@ class FluxTransformer2DModel(torch.nn.Module):
                 m = torch.empty(B, 6 * d, dtype=BF16, device=dev)
                 ops.skinny_linear(st, self.W(f"{p}.{norm}.linear.weight"), self.W(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
             mods[name] = m
-            Xs = self._stream_rows(w.X, w, name, d)
+            Xs = self._stream_rows(w.X if x_in is None else x_in, w, name, d)
             M = B * rows
             nrm = (w.nrm if save is None else save["nrm1"])[row0[name]:row0[name] + M]
             qkv = w.qkv[row0[name]:row0[name] + M]
@@ -428,19 +429,17 @@ class FluxTransformer2DModel(torch.nn.Module):
             ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
                              w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
-        if replay:
-            w.O.copy_(keep["O"])
-            w.lse.copy_(keep["lse"])
-        else:
-            self._attn(w, w.O, keep["lse"] if keep is not None else (w.lse if save is not None else None), d, w.S * d)
-            if keep is not None:
-                keep["O"].copy_(w.O)
+        # the attention output lives in the block's keep buffer when there is one (written here, read by the backward):
+        # no copy between the workspace and the kept tensor
+        O_buf = keep["O"] if keep is not None else w.O
+        if not replay:
+            self._attn(w, O_buf, keep["lse"] if keep is not None else (w.lse if save is not None else None), d, w.S * d)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m = mods[name]
             M = B * rows
             sl = slice(row0[name], row0[name] + M)
             Xs = self._stream_rows(w.X, w, name, d)
-            Os = self._stream_rows(w.O, w, name, d)
+            Os = self._stream_rows(O_buf, w, name, d)
             nrm = (w.nrm if save is None else save["nrm2"])[sl]
             hid = w.hid[sl]
             aux1 = aux2 = hpre = None
@@ -467,8 +466,8 @@ class FluxTransformer2DModel(torch.nn.Module):
                          EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
         return mods
 
-    def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None, keep=None, replay=False):
-        """`keep` / `replay`: as in `_double_block`, with per-block buffers {O, lse, y_attn}."""
+    def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None, keep=None, replay=False, x_in=None):
+        """`keep` / `replay` / `x_in`: as in `_double_block`, with per-block buffers {O, lse, y_attn}."""
         cfg, d, H = self.cfg, self.cfg.dim, self.cfg.num_attention_heads
         p = f"single_transformer_blocks.{i}"
         B, S = w.B, w.S
@@ -478,7 +477,7 @@ class FluxTransformer2DModel(torch.nn.Module):
         else:
             m = torch.empty(B, 3 * d, dtype=BF16, device=self.store.device)
             ops.skinny_linear(st, self.W(f"{p}.norm.linear.weight"), self.W(f"{p}.norm.linear.bias"), m, 3 * d, d)
-        Xa = Rows(w.X, M, d, S, S * d)
+        Xa = Rows(w.X if x_in is None else x_in, M, d, S, S * d)
         nrm = w.nrm if save is None else save["nrm1"]
         ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, nrm, d)
         ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
@@ -492,8 +491,7 @@ class FluxTransformer2DModel(torch.nn.Module):
                          w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward
-            w.cat[:, :, :d].copy_(keep["O"])
-            w.lse.copy_(keep["lse"])
+            w.cat[:, :, :d].copy_(keep["O"])         # (the wgrad of proj_out reads [O | mlp] as one [M, 5d] operand)
             return m
         self._attn(w, w.cat, keep["lse"] if keep is not None else (w.lse if save is not None else None), 5 * d, S * 5 * d)
         if keep is not None:

@@ -128,12 +128,22 @@ class FluxFunction(torch.autograd.Function):
             blk += 1
         tr.x_final.copy_(w.X)
         out, e = model._head(w, st)
+        # the saved activations live in the model's shared per-shape workspace: ONE pending backward per model at a time
+        # (INTEGRATION.md).  A second grad-enabled forward before this one's backward would overwrite them: stamped here,
+        # checked in backward.
+        w.train.generation = getattr(w.train, "generation", 0) + 1
+        ctx.generation = w.train.generation
         ctx.model, ctx.w, ctx.tr = model, w, tr
         ctx.saved = dict(ehs=ehs, in16=w.in16.clone(), temb=temb, st=st, keep=keep, cos=cos, sin=sin, mods=mods, e=e)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if getattr(ctx.w.train, "generation", None) != ctx.generation:
+            from ._lib import MgxError
+            raise MgxError("FluxTransformer2DModel: the activations of this forward pass were overwritten by a later "
+                           "grad-enabled forward of the same model (one pending backward per model; call backward() "
+                           "before the next training forward)")
         _backward(ctx.model, ctx.w, ctx.tr, ctx.saved, dout.contiguous().to(BF16))
         return (None,) * 9
 
@@ -222,10 +232,13 @@ def _backward(model, w, tr, sv, dout):
         blk = cfg.num_layers + i
         p = f"single_transformer_blocks.{i}"
         m = sv["mods"][blk]
-        w.X.copy_(tr.block_in[blk])
         kept = tr.keep[blk] if tr.keep else None
         save = dict(save0, y_attn=kept["y_attn"]) if kept else save0
-        model._single_block(i, w, st_, cos, sin, save=save, mod_in=m, keep=kept, replay=kept is not None)
+        if kept is None:
+            w.X.copy_(tr.block_in[blk])                        # full recompute rewrites the residual stream
+        model._single_block(i, w, st_, cos, sin, save=save, mod_in=m, keep=kept, replay=kept is not None,
+                            x_in=tr.block_in[blk] if kept is not None else None)
+        lse_b = kept["lse"] if kept is not None else w.lse
         dmod = torch.empty(B, 3 * d, dtype=BF16, device=dev)
         x_in = Rows(tr.block_in[blk], M, d, S, S * d)
         dXr = Rows(tr.dX, M, d, S, S * d)
@@ -244,15 +257,12 @@ def _backward(model, w, tr, sv, dout):
         ops.gemm(dyr, Wt[0:d], None, Rows(dcat, M, 5 * d), d, d, EPI_BIAS)
         ops.gemm(dyr, Wt[d:5 * d], None, Rows(dbig[0, 3 * d:], M, 7 * d), 4 * d, d, EPI_DGELU, aux=save["hid_pre"],
                  ldaux=4 * d)
-        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, w.lse, tr.delta, tr.dOt, tr.dQ, tr.dK,
+        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK,
                      tr.dV, B, H, S, Sp, 5 * d, S * 5 * d, scale)
-        # qk norm / rope backward writes [dq|dk|dv] into a [M, 3d] matrix: stage through qkv-shaped scratch, then
-        # place it in dbig[:, :3d]
-        dqkv = tr.dCt[:M * 3 * d].view(M, 3 * d)
+        # qk norm / rope backward writes [dq|dk|dv] straight into columns 0..3d of the [M, 7d] staging matrix
         ops.qk_norm_rope_bwd(w.qkv, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
-                             tr.dQ, tr.dK, tr.dV, dqkv, store.view(g32, f"{p}.attn.norm_q.weight"),
-                             store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0)
-        dbig[:, :3 * d].copy_(dqkv)
+                             tr.dQ, tr.dK, tr.dV, dbig, store.view(g32, f"{p}.attn.norm_q.weight"),
+                             store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0, ld_dqkv=7 * d)
         dbr = Rows.of(dbig)
         _wgrad(model, tr, Rows.of(save["nrm1"]), d, dbr, 7 * d, f"{p}.attn.to_q.weight", f"{p}.attn.to_q.bias", rows=True)
         _dgrad(model, tr, dbr, 7 * d, d, f"{p}.attn.to_q.weight", Rows.of(tr.dnrm), rows=True)
@@ -268,10 +278,13 @@ def _backward(model, w, tr, sv, dout):
     for i in reversed(range(cfg.num_layers)):
         p = f"transformer_blocks.{i}"
         mods = sv["mods"][i]
-        w.X.copy_(tr.block_in[i])
         kept = tr.keep[i] if tr.keep else None
         save = dict(save0, y_attn=kept["y_attn"], y_ff=kept["y_ff"], x_mid=kept["x_mid"]) if kept else save0
-        model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods, keep=kept, replay=kept is not None)
+        if kept is None:
+            w.X.copy_(tr.block_in[i])                          # full recompute rewrites the residual stream
+        model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods, keep=kept, replay=kept is not None,
+                            x_in=tr.block_in[i] if kept is not None else None)
+        O_b, lse_b = (kept["O"], kept["lse"]) if kept is not None else (w.O, w.lse)
         dmods = {k: torch.empty(B, 6 * d, dtype=BF16, device=dev) for k in ("img", "txt")}
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m, dm = mods[name], dmods[name]
@@ -296,9 +309,9 @@ def _backward(model, w, tr, sv, dout):
                                 dm[:, 3 * d:4 * d], dm[:, 4 * d:5 * d], d)
             # ---- attention branch: x_mid = x_in + gate_msa * to_out(O)
             ops.gate_bwd(dXs, save["y_attn"][sl], m[:, 2 * d:3 * d], 6 * d, tr.dy[sl], dm[:, 2 * d:3 * d], B, rows, d)
-            _wgrad(model, tr, srows(w.O, name, d), d, dyr, d, f"{p}.attn.{outn}.weight", f"{p}.attn.{outn}.bias")
+            _wgrad(model, tr, srows(O_b, name, d), d, dyr, d, f"{p}.attn.{outn}.weight", f"{p}.attn.{outn}.bias")
             _dgrad(model, tr, dyr, d, d, f"{p}.attn.{outn}.weight", srows(dO3, name, d))
-        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.O, dO3, w.lse, tr.delta, tr.dOt, tr.dQ, tr.dK, tr.dV,
+        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], O_b, dO3, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK, tr.dV,
                      B, H, S, Sp, d, S * d, scale)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m, dm = mods[name], dmods[name]

@@ -90,11 +90,13 @@ def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s
                                      ptr(V), ptr(Qt), ptr(Kt), B, H, S, Sp, rows_per_batch, s0, stream()))
 
 
-def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0):
+def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0, ld_dqkv=None):
+    """`dqkv`: a tensor whose data_ptr() is the first element of the [rows, >= 3d] output; `ld_dqkv` its row stride in
+    elements (default: 3d, a plain matrix)."""
     ws = scratch("qk_bwd", lib().mgx_qk_norm_rope_bwd_workspace(B, H, rows_per_batch), F32, qkv.device)
     check(lib().mgx_qk_norm_rope_bwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
-                                     ptr(dV), ptr(dqkv), ptr(gwq), ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0,
-                                     stream()))
+                                     ptr(dV), dqkv.data_ptr(), qkv.shape[-1] if ld_dqkv is None else ld_dqkv, ptr(gwq),
+                                     ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0, stream()))
 
 
 def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):

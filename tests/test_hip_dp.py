@@ -90,3 +90,28 @@ def _check_two_rank_results(out):
     assert res0[5]["Synthetic"] == pytest.approx(torch.cat([r1, r2]).mean().item(), rel=1e-6)
     assert res0[5]["HeadB"] == pytest.approx(torch.cat([torch.tensor([0.7, 0.1, 0.5, 0.3]), 2 * torch.tensor([0.7, 0.1, 0.5, 0.3])]).mean().item(), rel=1e-6)
     assert all(x == x for x in (res0[0], res0[1], res0[2]))
+
+
+def test_rccl_single_rank_smoke():
+    """RCCL itself (torch.distributed backend "nccl" on ROCm), which the N > 1 bench uses: one rank on this GPU -- the
+    communicator initialises and the collectives of the train step run.  (Two RCCL ranks cannot share one GPU; the multi-rank
+    logic is covered over gloo above.)"""
+    import subprocess
+    import sys
+
+    from helpers import free_port
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "from mixgrpo_amd import dist_utils as DU\n"
+        "t = torch.arange(8, dtype=torch.float32, device=dev)\n"
+        "dist.all_reduce(t); assert t.tolist() == list(range(8))\n"
+        "assert DU.gather_tensor(t).tolist() == list(range(8))\n"
+        "b = torch.ones(1 << 20, dtype=torch.bfloat16, device=dev); w = dist.all_reduce(b, async_op=True); w.wait()\n"
+        "torch.cuda.synchronize(); assert float(b.float().sum()) == float(1 << 20)\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]

@@ -309,3 +309,25 @@ def test_full_width_blocks_vs_oracle():
     worst.sort(reverse=True)
     assert dots / math.sqrt(nh * no) > 0.999, (dots / math.sqrt(nh * no), worst[:5])
     assert worst[0][0] < 5e-2, worst[:8]
+
+
+def test_second_forward_before_backward_is_refused():
+    """The training forward keeps its activations in the model's shared workspace: a second grad-enabled forward before the
+    first one's backward overwrites them, so that backward must fail loudly instead of returning wrong gradients."""
+    from mixgrpo_amd._lib import MgxError
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    cfg = FluxConfig(**small_cfg(1, 1))
+    m = FluxTransformer2DModel(cfg, device="cuda").init_synthetic(seed=1, std=0.05)
+    m.train()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 16, 64, generator=g).cuda()
+    kw = dict(encoder_hidden_states=(0.1 * torch.randn(1, 8, 64, generator=g)).bfloat16().cuda(),
+              timestep=torch.tensor([0.5]).cuda(), guidance=torch.tensor([3.5]).bfloat16().cuda(),
+              txt_ids=torch.zeros(8, 3).cuda(), pooled_projections=torch.randn(1, 32, generator=g).bfloat16().cuda(),
+              img_ids=torch.zeros(16, 3).cuda(), joint_attention_kwargs=None, return_dict=False)
+    out1 = m(hidden_states=x, **kw)[0]
+    out2 = m(hidden_states=x * 0.5, **kw)[0]
+    with pytest.raises(MgxError, match="overwritten"):
+        out1.float().sum().backward()
+    out2.float().sum().backward()                         # the latest forward's backward is fine
+    assert m.flat_param.grad is not None and torch.isfinite(m.flat_param.grad).all()
