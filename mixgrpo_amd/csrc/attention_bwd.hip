@@ -13,6 +13,7 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -35,6 +36,25 @@ __device__ __forceinline__ int rm_off(int row, int chunk) { return row * 256 + (
 // (both checked exhaustively against the ds_read_b128 lane groups and the ds_write_b64 groups).
 __device__ __forceinline__ int t64_off(int d, int slot) { return d * 128 + ((slot ^ ((d >> 1) & 7)) << 4); }
 __device__ __forceinline__ int t32_off(int d, int slot) { return d * 64 + ((slot ^ (((d >> 2) ^ (d >> 1)) & 3)) << 4); }
+
+// Staging loads go through buffer descriptors (wave-uniform base in SGPRs + ONE loop-invariant 32-bit lane offset + a scalar
+// tile offset): the 64-bit per-lane pointers of plain loads cost ~2 VGPRs each in kernels that sit at the 256-register
+// limit (their spill reloads inside the tile loop also drain the load queue), and rows beyond the tensor read as zeros
+// (out-of-range records) instead of needing a clamp per tile.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ auto buf_rsrc(const void* p, long bytes) {
+  const unsigned n = bytes > 0xfffffff0L ? 0xfffffff0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
+}
+template <typename R>
+__device__ __forceinline__ uint4 buf_ld16(R rs, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <typename R>
+__device__ __forceinline__ float buf_ld_f32(R rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+}
 
 __device__ __forceinline__ void xcd_remap(int& bid, int nwg) {
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -143,20 +163,31 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   uint4 rq, rdo, rqt, rdot;
   float rl = 0.f;
   const int nqt = (g.S + 31) / 32;
+  const auto rs_q = buf_rsrc(Qp, (long)g.S * HD * 2);                               // rows >= S read as zeros
+  const auto rs_do = buf_rsrc(dOp, ((long)(g.S - 1) * g.ldo + HD) * 2);
+  const auto rs_qt = buf_rsrc(Qtp, (long)HD * g.Sp * 2);
+  const auto rs_dot = buf_rsrc(dOtp, (long)HD * g.Sp * 2);
+  const auto rs_lse = buf_rsrc(g.lse + bhS, (long)g.S * 4);
+  const auto rs_dlt = buf_rsrc(g.delta + bhS, (long)g.S * 4);
+  const unsigned vo_q = (unsigned)(s_row * HD + s_chunk * 8) * 2, vo_do = (unsigned)(s_row * g.ldo + s_chunk * 8) * 2;
+  const unsigned vo_t = (unsigned)(s_d * g.Sp + s_c16 * 8) * 2, vo_l = (unsigned)(tid & 31) * 4;
+  float rl2 = 0.f;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(wid) == 0;
+  const float inv_scale = 1.0f / g.scale;
 #define DKV_LOAD(t)                                                                                   \
   do {                                                                                                \
-    const int q_base = (t) * 32;                                                                      \
-    int qr = q_base + s_row;                                                                          \
-    if (qr >= g.S) qr = g.S - 1;                                                                      \
-    rq = *reinterpret_cast<const uint4*>(Qp + (long)qr * HD + s_chunk * 8);                           \
-    rdo = *reinterpret_cast<const uint4*>(dOp + (long)qr * g.ldo + s_chunk * 8);                      \
-    rqt = *reinterpret_cast<const uint4*>(Qtp + (long)s_d * g.Sp + q_base + s_c16 * 8);               \
-    rdot = *reinterpret_cast<const uint4*>(dOtp + (long)s_d * g.Sp + q_base + s_c16 * 8);             \
-    if (tid < 64) {                                                                                   \
-      int qq = q_base + (tid & 31);                                                                   \
-      const bool ok = qq < g.S;                                                                       \
-      if (!ok) qq = g.S - 1;                                                                          \
-      rl = (tid < 32) ? (ok ? g.lse[bhS + qq] * 1.4426950408889634f : INFINITY) : g.delta[bhS + qq];  \
+    const unsigned q_base = (unsigned)(t) * 32;                                                       \
+    rq = buf_ld16(rs_q, vo_q, q_base * (HD * 2));                                                     \
+    rdo = buf_ld16(rs_do, vo_do, q_base * (unsigned)(g.ldo * 2));                                     \
+    rqt = buf_ld16(rs_qt, vo_t, q_base * 2);                                                          \
+    rdot = buf_ld16(rs_dot, vo_t, q_base * 2);                                                        \
+    /* lse and delta of the tile's 32 queries: loaded unconditionally by every thread (both, 4 bytes each) and only   \
+       turned into the staged value at DKV_STORE time.  (A load inside `if (tid < 64) { ... }` with arithmetic on its  \
+       result made hipcc wait vmcnt(0) right there: the four staging loads just issued were drained at the top of     \
+       EVERY q-tile, ~1 us of a 2.6 us tile.) */                                                      \
+    if (wave0) {   /* wave-uniform (scalar branch): the other seven waves issue four loads, not six */        \
+      rl = buf_ld_f32(rs_lse, vo_l, q_base * 4);                                                      \
+      rl2 = buf_ld_f32(rs_dlt, vo_l, q_base * 4);                                                     \
     }                                                                                                 \
   } while (0)
 #define DKV_STORE(buf)                                                                                \
@@ -169,63 +200,125 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
     *reinterpret_cast<uint2*>(base + 16384 + t32_off(s_d, (s_c16 >> 1) * 2 + 1) + (s_c16 & 1) * 8) = make_uint2(rqt.z, rqt.w); \
     *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, (s_c16 >> 1) * 2) + (s_c16 & 1) * 8) = make_uint2(rdot.x, rdot.y);   \
     *reinterpret_cast<uint2*>(base + 24576 + t32_off(s_d, (s_c16 >> 1) * 2 + 1) + (s_c16 & 1) * 8) = make_uint2(rdot.z, rdot.w); \
-    if (tid < 64) reinterpret_cast<float*>(base + 32768)[tid] = rl;                                   \
+    /* staged as the INITIAL ACCUMULATORS of the S and dP chains: -lse / scale (rows beyond S: -inf -> P = 0) and      \
+       -delta; S' = Q K^T - lse / scale then gives P = exp2(scale_log2e * S') with no subtraction and no LDS read in the \
+       VALU phase (in-kernel stamps: that phase was 30 % of a q-tile, most of it waiting for these broadcast reads) */  \
+    if (wave0)                                                                                        \
+      reinterpret_cast<float*>(base + 32768)[tid] =                                                   \
+          (tid < 32) ? ((nt_ * 32 + tid < g.S) ? -rl * inv_scale : -INFINITY) : -rl2;                 \
   } while (0)
 
+  // (Measured and dropped: `s_setprio 1` for the second-dispatched half of the waves, which loses the VALU arbitration to
+  // the older half in every phase -- stamps: 1476 vs 1048 cycles in the exp / dS phase -- either statically or alternating
+  // inside a tile: the favoured half simply takes over the other's timing, 7.6 ms either way.)
   DKV_LOAD(0);
-  DKV_STORE(0);
+  { const int nt_ = 0; DKV_STORE(0); }
   __syncthreads();
   // see attention.hip: make the pre-loop fragment loads provably complete so the loop's MFMAs are not fenced behind
   // the staging loads
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
   int cur = 0;
+#ifdef MGX_DIAG_DKV_STAMPS   /* diagnostic build (scratch/ only): where a q-tile's cycles go; sums land in the dQ buffer */
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(k_)                                                                  \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long now_;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    tsum[k_] += now_ - tlast;                                                      \
+    tlast = now_;                                                                  \
+  } while (0)
+  unsigned long long tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#else
+#define STAMP(k_) do {} while (0)
+#endif
   auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
-    if (t + 1 < nqt) DKV_LOAD(t + 1);
+    STAMP(0);
     const char* base = smem + cur * DKV_STAGE;
-    const float* lse2 = reinterpret_cast<const float*>(base + 32768);
-    const float* dlt = lse2 + 32;
+    const float* nls = reinterpret_cast<const float*>(base + 32768);     // -lse / scale per query row of the tile
+    const float* ndl = nls + 32;                                         // -delta
     f32x16 s, dp;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const s16x8 qa = *reinterpret_cast<const s16x8*>(base + rm_off(r, ks * 2 + h));
-      const s16x8 da = *reinterpret_cast<const s16x8*>(base + 8192 + rm_off(r, ks * 2 + h));
-      const s16x8 vfk = *reinterpret_cast<const s16x8*>(vfrag + ks * 1024);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vfk, dp, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {        // accumulator register 4j + e holds query row 8j + 4h + e
+      const float4 a = *reinterpret_cast<const float4*>(nls + 8 * j + 4 * h);
+      const float4 b2 = *reinterpret_cast<const float4*>(ndl + 8 * j + 4 * h);
+      s[4 * j] = a.x; s[4 * j + 1] = a.y; s[4 * j + 2] = a.z; s[4 * j + 3] = a.w;
+      dp[4 * j] = b2.x; dp[4 * j + 1] = b2.y; dp[4 * j + 2] = b2.z; dp[4 * j + 3] = b2.w;
     }
+    // Fragment reads run ONE k-step ahead of their MFMAs, in two register sets, the order pinned: written as
+    // "read; read; read; mfma; mfma" per k-step hipcc waits for the reads it has just issued (lgkmcnt(0) in front of
+    // every MFMA pair), so each k-step exposed the full LDS latency and the matrix pipe idled between pairs.
+    {
+      s16x8 qa[2], da[2], vk;                     // (a second set of V fragments spills a K fragment into the loop)
+      qa[0] = *reinterpret_cast<const s16x8*>(base + rm_off(r, h));
+      da[0] = *reinterpret_cast<const s16x8*>(base + 8192 + rm_off(r, h));
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        vk = *reinterpret_cast<const s16x8*>(vfrag + ks * 1024);          // needed by the SECOND MFMA of this k-step
+        if (ks + 1 < 8) {
+          qa[(ks + 1) & 1] = *reinterpret_cast<const s16x8*>(base + rm_off(r, (ks + 1) * 2 + h));
+          da[(ks + 1) & 1] = *reinterpret_cast<const s16x8*>(base + 8192 + rm_off(r, (ks + 1) * 2 + h));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks & 1], kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks & 1], vk, dp, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // next q-tile's staging loads: issued HERE, not at the top of the tile -- their 18 registers would be live through the
+    // S / dP phase, the register peak of the kernel (one K fragment was spilled into the loop); Q / dO tiles are L2 hits
+    // (every key block of the (batch, head) reads them) and have the exp and dV / dK phases to land
+    if (t + 1 < nqt) DKV_LOAD(t + 1);
+    STAMP(1);
     // P[q][key] and dS[q][key]; q = (i&3) + 8*(i>>2) + 4h (rows), key = this lane's column
     uint32_t pb[8], dsb[8];
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
-      const int qa = (i & 3) + 8 * (i >> 2) + 4 * h, qb = qa + 1;
-      float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e - lse2[qa]);       // rows beyond S carry lse = +inf -> P = 0
-      float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e - lse2[qb]);
+      float p0 = __builtin_amdgcn_exp2f(s[i] * g.scale_log2e);                  // rows beyond S: S' = -inf -> P = 0
+      float p1 = __builtin_amdgcn_exp2f(s[i + 1] * g.scale_log2e);
       if (MASK && !key_valid) p0 = p1 = 0.f;
-      const float d0 = p0 * (dp[i] - dlt[qa]) * g.scale;
-      const float d1 = p1 * (dp[i + 1] - dlt[qb]) * g.scale;
+      const float d0 = p0 * dp[i] * g.scale;
+      const float d1 = p1 * dp[i + 1] * g.scale;
       pb[i >> 1] = pack_bf16(p0, p1);
       dsb[i >> 1] = pack_bf16(d0, d1);
     }
+    STAMP(2);
+    // dV^T += dO^T P, dK^T += Q^T dS: 16 MFMAs, each with ONE operand from LDS (dOt / Qt images).  The reads run two
+    // MFMAs ahead through a ring of three fragment registers (same reason as above: "read; mfma" pairs serialise into
+    // read -> lgkmcnt(0) -> MFMA, one exposed LDS round trip per MFMA).
+    {
+      s16x8 pf[2], df[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const s16x8 pf = __builtin_bit_cast(s16x8, make_uint4(pb[4 * s2], pb[4 * s2 + 1], pb[4 * s2 + 2], pb[4 * s2 + 3]));
-      const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
-      const int slot = s2 * 2 + h;   // queries 16 s2 + 4h + {0..3} and + 8
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[s2] = __builtin_bit_cast(s16x8, make_uint4(pb[4 * s2], pb[4 * s2 + 1], pb[4 * s2 + 2], pb[4 * s2 + 3]));
+        df[s2] = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
+      }
+      // MFMA i (0..15): s2 = i >> 3, dt = (i >> 1) & 3, which = i & 1 (0: dV from the dOt image, 1: dK from the Qt image)
+      auto frag = [&](int i) __attribute__((always_inline)) {
+        const int s2 = i >> 3, dt = (i >> 1) & 3, which = i & 1;
+        return *reinterpret_cast<const s16x8*>(base + (which ? 16384 : 24576) + t32_off(dt * 32 + r, s2 * 2 + h));
+      };
+      s16x8 fr[3];                                // (a ring of four fragments spills one K fragment into the loop)
+      fr[0] = frag(0); fr[1] = frag(1);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int d = dt * 32 + r;
-        const s16x8 a = *reinterpret_cast<const s16x8*>(base + 24576 + t32_off(d, slot));
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[dt], 0, 0, 0);
-        const s16x8 bq = *reinterpret_cast<const s16x8*>(base + 16384 + t32_off(d, slot));
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, df, dk[dt], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        if (i + 2 < 16) fr[(i + 2) % 3] = frag(i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int s2 = i >> 3, dt = (i >> 1) & 3;
+        if (i & 1) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3], df[s2], dk[dt], 0, 0, 0);
+        else dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3], pf[s2], dv[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (t + 1 < nqt) DKV_STORE(cur ^ 1);
+    STAMP(3);
+    if (t + 1 < nqt) { const int nt_ = t + 1; DKV_STORE(cur ^ 1); }
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     cur ^= 1;
   };
   if (key0 + 32 > g.S) {          // wave-uniform: only the ragged last key block carries the per-key mask
@@ -233,6 +326,13 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   } else {
     for (int t = 0; t < nqt; ++t) tile(t, std::false_type{});
   }
+#ifdef MGX_DIAG_DKV_STAMPS
+  if (lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.dQ) + ((long)blockIdx.x * 8 + wid) * 8;
+    for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = tsum[k_];
+  }
+#endif
+#undef STAMP
   const int key = key0 + r;
   if (key < g.S) {
     bf16_raw* dkp = g.dK + (bhS + key) * HD;
@@ -278,6 +378,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
     qf[ks] = *reinterpret_cast<const s16x8*>(g.Q + (bhS + qrow) * HD + ks * 16 + h * 8);
     dof[ks] = *reinterpret_cast<const s16x8*>(dOp + ks * 16 + h * 8);
   }
+  // (the dK / dV kernel's "row constants as initial accumulators" does not pay here: the constants are per-lane scalars
+  // already, and 32 accumulator registers that are live before their chains cost this kernel its staging registers)
   const float lse2 = g.lse[bhS + qrow] * 1.4426950408889634f;
   const float dlt = g.delta[bhS + qrow];
   f32x16 dq[4];
@@ -290,18 +392,19 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
   const int vc_d0 = tid >> 3, vc_chunk = tid & 7;
   uint4 sk0, sk1, sv0, sv1, st0, st1;
   const int ntiles = (g.S + 63) / 64;
+  const auto rs_k = buf_rsrc(Kp, (long)g.S * HD * 2);                               // rows >= S read as zeros (keys masked below)
+  const auto rs_v = buf_rsrc(Vp, (long)g.S * HD * 2);
+  const auto rs_kt = buf_rsrc(Ktp, (long)HD * g.Sp * 2);
+  const unsigned vo_k = (unsigned)(kc_key0 * HD + kc_chunk * 8) * 2, vo_kt = (unsigned)(vc_d0 * g.Sp + vc_chunk * 8) * 2;
 #define DQ_LOAD(t)                                                                                  \
   do {                                                                                              \
-    const int key_base = (t) * 64;                                                                  \
-    int ka = key_base + kc_key0, kb_ = key_base + kc_key0 + 32;                                     \
-    if (ka >= g.S) ka = g.S - 1;                                                                    \
-    if (kb_ >= g.S) kb_ = g.S - 1;                                                                  \
-    sk0 = *reinterpret_cast<const uint4*>(Kp + (long)ka * HD + kc_chunk * 8);                       \
-    sk1 = *reinterpret_cast<const uint4*>(Kp + (long)kb_ * HD + kc_chunk * 8);                      \
-    sv0 = *reinterpret_cast<const uint4*>(Vp + (long)ka * HD + kc_chunk * 8);                       \
-    sv1 = *reinterpret_cast<const uint4*>(Vp + (long)kb_ * HD + kc_chunk * 8);                      \
-    st0 = *reinterpret_cast<const uint4*>(Ktp + (long)vc_d0 * g.Sp + key_base + vc_chunk * 8);       \
-    st1 = *reinterpret_cast<const uint4*>(Ktp + (long)(vc_d0 + 64) * g.Sp + key_base + vc_chunk * 8); \
+    const unsigned key_base = (unsigned)(t) * 64;                                                   \
+    sk0 = buf_ld16(rs_k, vo_k, key_base * (HD * 2));                                                \
+    sk1 = buf_ld16(rs_k, vo_k, (key_base + 32) * (HD * 2));                                         \
+    sv0 = buf_ld16(rs_v, vo_k, key_base * (HD * 2));                                                \
+    sv1 = buf_ld16(rs_v, vo_k, (key_base + 32) * (HD * 2));                                         \
+    st0 = buf_ld16(rs_kt, vo_kt, key_base * 2);                                                     \
+    st1 = buf_ld16(rs_kt, vo_kt + (unsigned)(64 * g.Sp * 2), key_base * 2);                         \
   } while (0)
 #define DQ_STORE(buf)                                                                               \
   do {                                                                                              \
@@ -334,12 +437,25 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+      // fragment reads two k-steps ahead of their MFMAs, three register sets, order pinned (see attn_bwd_dkv_kernel)
+      {
+        s16x8 ka[3], va[3];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const s16x8 ka = *reinterpret_cast<const s16x8*>(base + rm_off(kb * 32 + r, ks * 2 + h));
-        const s16x8 va = *reinterpret_cast<const s16x8*>(base + 16384 + rm_off(kb * 32 + r, ks * 2 + h));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dp, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+          ka[ks] = *reinterpret_cast<const s16x8*>(base + rm_off(kb * 32 + r, ks * 2 + h));
+          va[ks] = *reinterpret_cast<const s16x8*>(base + 16384 + rm_off(kb * 32 + r, ks * 2 + h));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + 2 < 8) {
+            ka[(ks + 2) % 3] = *reinterpret_cast<const s16x8*>(base + rm_off(kb * 32 + r, (ks + 2) * 2 + h));
+            va[(ks + 2) % 3] = *reinterpret_cast<const s16x8*>(base + 16384 + rm_off(kb * 32 + r, (ks + 2) * 2 + h));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % 3], qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks % 3], dof[ks], dp, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       uint32_t dsb[8];
 #pragma unroll
@@ -353,15 +469,23 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
         }
         dsb[i >> 1] = pack_bf16(p0 * (dp[i] - dlt) * g.scale, p1 * (dp[i + 1] - dlt) * g.scale);
       }
+      // dQ^T += K^T dS^T: 8 MFMAs with their Kt fragments three ahead in a ring of four
+      {
+        s16x8 df[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const s16x8 df = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
-        const int slot = (kb * 2 + s2) * 2 + h;   // keys 32 kb + 16 s2 + 4h + {0..3} and + 8
+        for (int s2 = 0; s2 < 2; ++s2)
+          df[s2] = __builtin_bit_cast(s16x8, make_uint4(dsb[4 * s2], dsb[4 * s2 + 1], dsb[4 * s2 + 2], dsb[4 * s2 + 3]));
+        auto frag = [&](int i) __attribute__((always_inline)) {       // i = 4 s2 + dt; keys 32 kb + 16 s2 + 4h + {0..3} and + 8
+          return *reinterpret_cast<const s16x8*>(base + 32768 + t64_off((i & 3) * 32 + r, (kb * 2 + (i >> 2)) * 2 + h));
+        };
+        s16x8 fr[4];
+        fr[0] = frag(0); fr[1] = frag(1); fr[2] = frag(2);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 32 + r;
-          const s16x8 a = *reinterpret_cast<const s16x8*>(base + 32768 + t64_off(d, slot));
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df, dq[dt], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+          if (i + 3 < 8) fr[(i + 3) & 3] = frag(i + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          dq[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], df[i >> 2], dq[i & 3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -408,7 +532,9 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   }
   const int nb = cdiv(S, 256) * H * B;
   attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
+#ifndef MGX_DIAG_DKV_STAMPS
   attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
+#endif
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
