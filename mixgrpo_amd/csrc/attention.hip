@@ -58,7 +58,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 // NW waves per workgroup (QB = 32*NW queries).  NW = 4 puts two independent workgroups on a CU (64 KiB LDS each): their
 // barriers are unrelated, so one workgroup's softmax VALU phase runs under the other's MFMA phase instead of the two
 // waves of a SIMD marching in lockstep.
-template <int NW, bool DEFER>
+// OVL: the P V product of the tile's first 32 keys (8 MFMAs) is issued BESIDE the exponentials of its last 32 keys, inside
+// one scheduling region with `sched_group_barrier` hints (1 MFMA : 2 v_exp : 5 other VALU per gap -- 36 issue cycles per
+// 32-cycle MFMA).  In-kernel stamps showed the softmax VALU phase (1100-1600 cycles per wave and tile) and the MFMA phases
+// (2 x ~600) adding up almost serially: both waves of a SIMD are in the same phase at the same time.
+template <int NW, bool DEFER, bool OVL = false>
 __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   constexpr int QB = QW * NW;
   constexpr int NCH = 1024 / (NW * 64);   // 16-byte chunks per thread per operand tile
@@ -141,9 +145,26 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   int cur = 0;
   // one K/V tile: S^T, online softmax, O^T accumulation.  Kept as a lambda over a compile-time MASK so the full
   // tiles carry no masking selects (hipcc if-converts a runtime "last tile" test into ~200 v_cndmask per tile).
+#ifdef MGX_DIAG_FWD_STAMPS   /* diagnostic build (scratch/ only): where a K/V tile's cycles go; sums land in the LSE buffer */
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#define STAMP(k_)                                                                  \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long now_;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    tsum[k_] += now_ - tlast;                                                      \
+    tlast = now_;                                                                  \
+  } while (0)
+#else
+#define STAMP(k_) do {} while (0)
+#endif
   auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
     if (t + 1 < ntiles) LOAD_KV(t + 1);
+    STAMP(0);
     const char* ks_ = smem + cur * (K_TILE_BYTES + V_TILE_BYTES);
     const char* vs_ = ks_ + K_TILE_BYTES;
 
@@ -170,6 +191,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[1], 0, 0, 0);
     }
+    STAMP(1);
     // first Vt fragments of the P V product: requested here so that they return underneath the softmax
     s16x8 vfr[2][4];
 #pragma unroll
@@ -215,8 +237,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
     const float mc = m_run * g.scale_log2e;
     float psum = 0.f;
     uint32_t pb[2][8];   // P^T as bf16 pairs: B-operand fragments, k-step s uses regs 8s..8s+7
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    auto exps = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         const float p0 = __builtin_amdgcn_exp2f(s[kb][i] * g.scale_log2e - mc);
@@ -224,15 +245,62 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
         psum += p0 + p1;
         pb[kb][i >> 1] = pack_bf16(p0, p1);
       }
+    };
+    auto pfrag = [&](int idx) __attribute__((always_inline)) {
+      const int kb = idx >> 1, s2 = idx & 1;
+      return __builtin_bit_cast(s16x8, make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]));
+    };
+    if constexpr (OVL) {
+      exps(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vfr[1][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, 2 + h));
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- one scheduling region: 8 MFMAs (keys 0..31) + the exponentials of keys 32..63 + the V fragments of idx 2
+      {
+        const s16x8 pf0 = pfrag(0), pf1 = pfrag(1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][dt], pf0, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vfr[0][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, 4 + h));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][dt], pf1, o[dt], 0, 0, 0);
+        exps(1);
+#pragma unroll
+        for (int k_ = 0; k_ < 8; ++k_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);     // 2 transcendental (v_exp_f32)
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // 5 other VALU
+          if (k_ == 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the four V fragment reads of idx 2
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      l_run = l_run * alpha + psum;
+      STAMP(2);
+#pragma unroll
+      for (int idx = 2; idx < 4; ++idx) {
+        const s16x8 pf = pfrag(idx);
+        if (idx + 1 < 4) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            vfr[(idx + 1) & 1][dt] = *reinterpret_cast<const s16x8*>(vs_ + v_off(dt * 32 + r, (idx + 1) * 2 + h));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[idx & 1][dt], pf, o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+    exps(0);
+    exps(1);
     l_run = l_run * alpha + psum;
+    STAMP(2);
 
     // ---- O^T += Vt P^T : A = Vt[d = 32*dt + r][slot (b = 2 kb + s2, h)]: the 8 keys of lane half h in the S^T
     // accumulator's order; the four fragments of step idx + 1 are requested before the MFMAs of step idx
 #pragma unroll
     for (int idx = 0; idx < 4; ++idx) {
-      const int kb = idx >> 1, s2 = idx & 1;
-      const uint4 u = make_uint4(pb[kb][4 * s2], pb[kb][4 * s2 + 1], pb[kb][4 * s2 + 2], pb[kb][4 * s2 + 3]);
-      const s16x8 pf = __builtin_bit_cast(s16x8, u);
+      const s16x8 pf = pfrag(idx);
       if (idx + 1 < 4) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -244,14 +312,27 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[idx & 1][dt], pf, o[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
+    STAMP(3);
     if (t + 1 < ntiles) STORE_KV(cur ^ 1);
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     cur ^= 1;
   };
   const int nfull = g.S / KB;
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntiles) tile(nfull, std::true_type{});
 
+#ifdef MGX_DIAG_FWD_STAMPS
+  if (lane == 0 && g.lse) {
+    // behind the real LSE area [B, H, S] (the diagnostic script allocates the buffer that much larger)
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.lse + (((long)g.B * g.H * g.S + 1) & ~1L)) +
+                              ((long)blockIdx.x * NW + wid) * 8;
+    for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = tsum[k_];
+  }
+#endif
+#undef STAMP
   // ---- finalize: row sum across the two half-waves, normalise, store O[q][h*128 + d]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -291,7 +372,9 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   static const int defer = getenv("MGX_ATTN_DEFER") ? atoi(getenv("MGX_ATTN_DEFER")) : 1;
   const int lds = 2 * (K_TILE_BYTES + V_TILE_BYTES);
   hipStream_t st = (hipStream_t)stream;
-  if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
+  static const int ovl = getenv("MGX_ATTN_OVL") ? atoi(getenv("MGX_ATTN_OVL")) : 1;
+  if (nw == 8 && defer && ovl) attn_fwd_kernel<8, true, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
+  else if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (nw == 8) attn_fwd_kernel<8, false><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (defer) attn_fwd_kernel<4, true><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
   else attn_fwd_kernel<4, false><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
