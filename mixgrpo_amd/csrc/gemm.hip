@@ -840,8 +840,15 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       const uint32_t sa_u = lds0 + aslot * TB, sw_u = lds0 + WBASE + wslot * TB;
       const uint32_t a_ad[2] = {sa_u + a_ro[0], sa_u + a_ro[1]}, w_ad[2] = {sw_u + w_ro[0], sw_u + w_ro[1]};
       // the four W pieces first thing (they must land within this iteration: every cycle of lead counts, +2-7 %)
+#ifdef MGX_GEMM_WSTAG   /* A/B variant: waves 4-7 issue their W pieces behind the second MFMA group instead, so that a SIMD's two
+                           waves are not both stalled in LDS-DMA issue right after the barrier */
+      if (wu < 4) {
+#endif
       PGLDS_W(wb_, cw[0], lw_); PGLDS_W(wb_, cw[1], lw_ + RS * 128);
       PGLDS_W(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_W(wb_, cw[3], lw_ + 3 * RS * 128);
+#ifdef MGX_GEMM_WSTAG
+      }
+#endif
       PIN();
       // head reads r1..r10, the two the first MFMA needs in front
       RD_W(0, 0); RD_A(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3); RD_A(0, 1);
@@ -862,6 +869,13 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
       WAIT2(4, fa[0][2], fa[0][3]);                                     // r7, r8 (r9..r12 may be in flight)
       MMA_GROUP(0, 1);
       PIN();
+#ifdef MGX_GEMM_WSTAG
+      if (wu >= 4) {
+        PGLDS_W(wb_, cw[0], lw_); PGLDS_W(wb_, cw[1], lw_ + RS * 128);
+        PGLDS_W(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_W(wb_, cw[3], lw_ + 3 * RS * 128);
+      }
+      PIN();
+#endif
       RD_W(1, 0); RD_W(1, 1); RD_W(1, 2); RD_W(1, 3); RD_A(1, 0); RD_A(1, 1);   // r13..r18
       PIN();
       WAIT2(8, fa[0][4], fa[0][5]);                                     // r9, r10
