@@ -299,7 +299,7 @@ def main():
             traffic_src = {"file": f"profiles/{pmc_name}", "shape": pmc["shape"],
                            "algorithmic_bytes_per_launch": pmc["algorithmic_bytes_per_launch"],
                            "effective_clock_ghz": pmc["effective_clock_ghz"], "mfma_busy_frac": pmc["mfma_busy_frac"]}
-        roofline = {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI> (bf16 MFMA 256x256x64 persistent, all epilogues) "
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel<EPI> (bf16 MFMA 256x256x64 persistent ping-pong, all epilogues) "
                                                 "+ gemm_kernel<EPI> (128x128x64, small shapes)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -52,6 +52,7 @@ struct GemmArgs {
   float beta;             // EPI_F32_ACC: C = beta*C + acc
   int rowwise_ok;         // all bf16 side operands are 16-byte addressable: the LDS-staged epilogue may be used
   int span32;             // both operands span < 4 GiB: the persistent kernel's 32-bit DMA source offsets are valid
+  int band;               // tile order of the persistent kernels (set in launch(): rule at gemm_persist_kernel)
 };
 
 // gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With tanh(u) = 2 s - 1, s = 1 / (1 + e^{-2u}):
@@ -654,7 +655,7 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
   // panel is fetched once (N = 3072, K = 15360: 1308 -> 1371 TFLOP/s against band 8) -- wider ones band 4 (4 x 8 rounds:
   // +0.7-1 % against 8 x 4; band 1 would put 32 W panels in a round: -3-4 %).  Few tile ROWS (the wgrad shapes with 3072
   // output rows): the mirror case, one band of all rows, every W panel once (+1 %).
-  const int band = tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4);
+  const int band = g.band;                // = tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4), launch()
   // tile list of this workgroup: the XCD (blockIdx & 7) owns a contiguous range of the banded tile order and its
   // workgroups take every (gridDim/8)-th tile of it
   const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
@@ -964,8 +965,256 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 #undef PGLDS_AUX
 }
 
+// ------------------------------------------------------------------------------------------ ping-pong kernel (the default)
+// Same tile, staging depth, tile order and register epilogue as gemm_persist_kernel, different K-loop.  A K-tile is TWO phases
+// of 32 MFMAs per wave, each phase = [load section | barrier | MFMA section | barrier], and the second half of the waves
+// (wm = 1: the SIMD partners of the first half) runs ONE barrier behind, so that on every SIMD one wave's MFMA section
+// coincides with its partner's load section (LDS fragment reads + four LDS-DMA pieces): the in-order stalls of DMA issue and
+// fragment reads never hold up a wave's own MFMAs.
+//   LA: W fragments (8) + A fragments of token half 0 (8); A pieces 0-3 of K-tile k+2
+//   MA: tokens 0-63 x features 0-63        LB: A fragments of token half 1 (8); W pieces 0-3 of K-tile k+2; vmcnt(8)
+//   MB: tokens 64-127 x features 0-63
+// LDS hazards by construction: A stage k+2 replaces stage k-1 (3 stages; last read in LB of k-1 -- of the late half during the
+// early half's MB of k-1 -- one barrier before the first LA of k); W stage k+2 replaces stage k (2 stages; last read in LA of k,
+// of the late half during the early half's MA of k, one barrier before the first LB of k).  vmcnt(8) at the end of LB leaves
+// this K-tile's eight pieces in flight: everything K-tile k+1 reads has landed in every wave before the barrier in front of
+// the first LA of k+1.
+// Measured (profiles/r02_pp_clock.log, in-kernel clock = d s_memtime / d s_memrealtime): 2423-2476 shader cycles per K-tile
+// against the matrix pipe's 2048 (83-85 % busy) at a clock the chip holds at 1.71-1.76 GHz under this load; the first
+// version of this loop with FOUR phases of 16 MFMAs (8 barriers per K-tile) ran 2622-2703 cycles at 1.82-1.87 GHz and
+// 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), gemm_persist_kernel 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
 template <int EPI>
-int launch(const GemmArgs& g, hipStream_t st) {
+__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
+  constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
+  constexpr int WBASE = 3 * TB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
+  const int nwg = tiles_m * tiles_n;
+  const int nkt = g.K / BK;
+  const int band = g.band;                // = tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4), launch()
+  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
+  const int q = nwg >> 3, rem = nwg & 7;
+  const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int xend = xbeg + (xcd < rem ? q + 1 : q);
+  int t_lin = xbeg + lane_in_xcd;
+  if (t_lin >= xend) return;
+
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const bool late = wu >= 4;
+  const int lrow = tid >> 3, lkc = tid & 7;
+  const int src_kc = swz(lrow, lkc);
+  const int wrow = wperm(lrow);
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef const __attribute__((address_space(1))) char gbl_char;
+  uint32_t ao[4], wo[4];
+  long m0, n0;
+#define TILE_COORDS(tl, M0, N0)                                            \
+  do {                                                                     \
+    const int per_band = band * tiles_n;                                   \
+    const int b0 = (tl) / per_band;                                        \
+    const int rows_in_band = min(band, tiles_m - b0 * band);               \
+    const int in_band = (tl) - b0 * per_band;                              \
+    M0 = (long)(b0 * band + in_band % rows_in_band) * TM;                  \
+    N0 = (long)(in_band / rows_in_band) * TN;                              \
+  } while (0)
+#define TILE_OFFS(M0, N0, AO, WO)                                                          \
+  do {                                                                                     \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
+      long mm = M0 + lrow + k_ * RS;                                                       \
+      if (mm >= g.M) mm = g.M - 1;                                                         \
+      AO[k_] = (uint32_t)((row_off(g.a, mm) + src_kc * 8) * 2);                            \
+      long nn = N0 + k_ * 64 + wrow;                                                       \
+      if (nn >= g.N) nn = g.N - 1;                                                         \
+      WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
+    }                                                                                      \
+  } while (0)
+#define PGLDS(base, off, off_lds) \
+  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef MGX_DIAG_PP_STAMPS    /* diagnostic build (scratch/ only): cycles per [section + barrier wait], summed per wave, into g.aux */
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  int tsec = 0;
+#define BAR()                                                                        \
+  do {                                                                               \
+    PIN(); __builtin_amdgcn_s_barrier(); PIN();                                      \
+    unsigned long long now_;                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory");   \
+    PIN();                                                                           \
+    if (tlast) tsum[tsec] += now_ - tlast;                                           \
+    tlast = now_;                                                                    \
+    tsec = (tsec + 1) & 7;                                                           \
+  } while (0)
+#else
+#define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
+#endif
+
+  uint32_t a_ro[2], w_ro[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_ro[ks] = (uint32_t)((wm * 128 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
+    w_ro[ks] = (uint32_t)(WBASE + (wn * 64 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
+  }
+#define LDA(ks, j) (*reinterpret_cast<const s16x8*>(smem + sa_ + a_ro[ks] + (j) * 2048))
+#define LDW(ks, i) (*reinterpret_cast<const s16x8*>(smem + sw_ + w_ro[ks] + (i) * 2048))
+#define MMA(i_, j_, W_, A_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_, A_, acc[i_][j_], 0, 0, 0)
+
+#ifdef MGX_TIMING_ONLY_PP_NODMA      /* diagnostic builds: WRONG results, timing only */
+#define PGLDS_K(base, off, off_lds) do { } while (0)
+#else
+#define PGLDS_K PGLDS
+#endif
+#ifdef MGX_TIMING_ONLY_PP_NOREADS
+#define LDA_K(ks, j) faA[ks][(j) & 3]
+#define LDW_K(ks, i) faA[ks][(i) & 3]
+#else
+#define LDA_K LDA
+#define LDW_K LDW
+#endif
+#ifdef MGX_DIAG_PP_CLOCK      /* diagnostic build: shader cycles and 100 MHz ticks of the whole workgroup, into g.aux */
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  TILE_COORDS(t_lin, m0, n0);
+  TILE_OFFS(m0, n0, ao, wo);
+  {  // prologue: A K-tiles 0, 1 -> A slots 0, 1; W K-tiles 0, 1 -> W slots 0, 1
+    const char* ab = reinterpret_cast<const char*>(g.A);
+    const char* wb = reinterpret_cast<const char*>(g.W);
+    const int la = wu * 1024, lw = WBASE + wu * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PGLDS(ab, ao[k], la + k * RS * 128);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PGLDS(wb, wo[k], lw + k * RS * 128);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PGLDS(ab + BK * 2, ao[k], TB + la + k * RS * 128);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PGLDS(wb + BK * 2, wo[k], TB + lw + k * RS * 128);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (late) __builtin_amdgcn_s_barrier();          // the late half runs one barrier behind from here on
+  int aslot = 0, wslot = 0;
+  while (true) {
+    const int t_next = t_lin + per_xcd_wg;
+    const bool has_next = t_next < xend;
+    long nm0 = 0, nn0 = 0;
+    uint32_t nao[4] = {ao[0], ao[1], ao[2], ao[3]}, nwo[4] = {wo[0], wo[1], wo[2], wo[3]};
+    if (has_next) {
+      TILE_COORDS(t_next, nm0, nn0);
+      TILE_OFFS(nm0, nn0, nao, nwo);
+    }
+    uint32_t ca[4] = {ao[0], ao[1], ao[2], ao[3]}, cw[4] = {wo[0], wo[1], wo[2], wo[3]};
+    f32x4 acc[NTL][MT];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool nxt = kt + 2 >= nkt;
+      const int k2 = nxt ? kt + 2 - nkt : kt + 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ca[k] = nxt ? nao[k] : ca[k];
+        cw[k] = nxt ? nwo[k] : cw[k];
+      }
+      const int a_dst = aslot == 0 ? 2 : aslot - 1;
+      const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)k2 * (BK * 2);
+      const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)k2 * (BK * 2);
+      const int la_ = a_dst * TB + wu * 1024, lw_ = WBASE + wslot * TB + wu * 1024;
+      const uint32_t sa_ = aslot * TB, sw_ = wslot * TB;
+      s16x8 faA[2][4], faB[2][4], fw[2][4];
+      // ---- LA
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[ks][i] = LDW_K(ks, i);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) faA[ks][j] = LDA_K(ks, j);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) PGLDS_K(ab_, ca[k], la_ + k * RS * 128);
+      BAR();
+      // ---- MA: tokens 0-63 x features 0-63
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) MMA(i, j, fw[ks][i], faA[ks][j]);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+      // ---- LB
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) faB[ks][j] = LDA_K(ks, 4 + j);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) PGLDS_K(wb_, cw[k], lw_ + k * RS * 128);
+      PIN();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      BAR();
+      // ---- MB: tokens 64-127 x features 0-63
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) MMA(i, 4 + j, fw[ks][i], faB[ks][j]);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+      aslot = aslot == 2 ? 0 : aslot + 1;
+      wslot ^= 1;
+    }
+    int el = lane, ew = wid;
+    asm volatile("" : "+v"(el), "+v"(ew));
+    // (measured on the four-phase version and dropped: both halves running their epilogues in the SAME barrier interval --
+    //  one extra barrier per half and tile -- is neutral; `s_setprio` around the MFMA sections is worth 2 %)
+    persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
+    if (!has_next) break;
+    t_lin = t_next;
+    m0 = nm0; n0 = nn0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();         // matches the late half's last barrier
+#ifdef MGX_DIAG_PP_CLOCK
+  if (EPI == EPI_BIAS && g.aux && tid == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.aux) + (long)blockIdx.x * 2;
+    dbg[0] = __builtin_amdgcn_s_memtime() - clk0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
+#ifdef MGX_DIAG_PP_STAMPS
+  if (EPI == EPI_BIAS && g.aux && lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.aux) + ((long)blockIdx.x * 8 + wid) * 8;
+    for (int k_ = 0; k_ < 8; ++k_) dbg[k_] = tsum[k_];
+  }
+#endif
+#undef TILE_COORDS
+#undef TILE_OFFS
+#undef PGLDS
+#undef PIN
+#undef BAR
+#undef PGLDS_K
+#undef LDA_K
+#undef LDW_K
+#undef LDA
+#undef LDW
+#undef MMA
+}
+
+template <int EPI>
+int launch(const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  {
+    const int tiles_m = cdiv(g.M, 256), tiles_n = cdiv(g.N, 256);
+    static const int band_env = getenv("MGX_GEMM_BAND") ? atoi(getenv("MGX_GEMM_BAND")) : 0;      // A/B only
+    g.band = band_env > 0 ? min(band_env, tiles_m) : (tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4));
+  }
   // the 256x256 tile needs enough tiles to fill most of the 256 CUs; skinny / small problems keep the 128x128 tile
   // (measured, scratch/bench_gemm_small.py: 168 tiles 843-935 vs 591-691 TFLOP/s, 120 tiles equal, 24-96 tiles slower)
   const long tiles_big = (long)cdiv(g.M, 256) * cdiv(g.N, 256);
@@ -975,14 +1224,17 @@ int launch(const GemmArgs& g, hipStream_t st) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
-  // MGX_GEMM_MODE=0 forces the 128x128 kernel everywhere (A/B and debugging)
-  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 6;
+  // MGX_GEMM_MODE (A/B and debugging): 0 forces the 128x128 kernel everywhere, 6 the persistent kernel of round 1 in
+  // place of the ping-pong kernel
+  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    gemm_persist_kernel<EPI><<<grid, 512, 163840, st>>>(g);
+    if (mode == 6) gemm_persist_kernel<EPI><<<grid, 512, 163840, st>>>(g);
+    else gemm_pp_kernel<EPI><<<grid, 512, 163840, st>>>(g);
   } else {
     gemm_kernel<EPI><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
