@@ -140,3 +140,30 @@ def test_gemm_full_size_linearity():
     assert torch.equal(outs[0] + outs[1], outs[2])          # every partial sum is exactly representable: bit-exact
     for rows in (slice(0, 512), slice(M // 2 - 256, M // 2 + 256), slice(M - 512, M)):     # first, middle and last tiles
         assert torch.equal(outs[0][rows], A1[rows].float() @ W.float().t())                 # of the workgroups' lists
+
+
+def test_round1_kernel_stays_selectable():
+    """`MGX_GEMM_MODE=6` (read once per process) selects round 1's persistent kernel for A/B runs: it must keep producing the
+    same Linear as the default ping-pong kernel (both within the bf16 tolerance of the fp32 reference; the two differ only in
+    the summation order inside a K-tile)."""
+    import os, subprocess, sys
+    code = (
+        "import sys, torch; sys.path.insert(0, '.')\n"
+        "from mixgrpo_amd import ops; from mixgrpo_amd.ops import Rows\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "M, N, K = 256 * 40 + 19, 2304, 448\n"
+        "A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda(); W = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()\n"
+        "b = (torch.randn(N, generator=g) * 0.2).bfloat16().cuda(); C = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')\n"
+        "ops.gemm(Rows.of(A), W, b, Rows.of(C), N, K, 0); torch.cuda.synchronize()\n"
+        "ref = (A.float() @ W.float().t() + b.float())\n"
+        "d = (C.float() - ref).abs(); tol = ref.abs() * 2.0 ** -7 + 2e-3\n"
+        "assert (d <= tol).all(), (d - tol).max().item()\n"
+        "print('OK')\n")
+    for mode in ("6", None):
+        env = dict(os.environ)
+        env.pop("MGX_GEMM_MODE", None)
+        if mode:
+            env["MGX_GEMM_MODE"] = mode
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "OK" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])
