@@ -9,7 +9,7 @@
 // (they price one part of a kernel by removing it).  They exist only together with -DMGX_DIAGNOSTIC_BUILD, which makes
 // mgx_version() negative: mixgrpo_amd/_lib.py refuses such a library, and mixgrpo_amd/build.py writes it to scratch/ only.
 #if (defined(MGX_TIMING_ONLY_NO_EPI_STORES) || defined(MGX_TIMING_ONLY_NO_EPILOGUE) || defined(MGX_TIMING_ONLY_NO_DMA) ||   \
-     defined(MGX_TIMING_ONLY_NO_FRAG_READS) || defined(MGX_TIMING_ONLY_MFMA32) || defined(MGX_TIMING_ONLY_NO_KTILE_SYNC) || \
+     defined(MGX_TIMING_ONLY_NO_FRAG_READS) || defined(MGX_TIMING_ONLY_MFMA32) || defined(MGX_TR_MAP16X4) || defined(MGX_TIMING_ONLY_NO_KTILE_SYNC) || \
      defined(MGX_TIMING_ONLY_NO_VMCNT) || defined(MGX_TIMING_ONLY_PP_NODMA) || defined(MGX_TIMING_ONLY_PP_NOREADS) || defined(MGX_TIMING_ONLY_NO_BARRIER) || defined(MGX_GEMM_COMPILER_WAITS) ||        \
      defined(MGX_GEMM_SETPRIO) || defined(MGX_GEMM_WSTAG) || defined(MGX_DIAG_DKV_STAMPS) || defined(MGX_DIAG_PP_STAMPS) || defined(MGX_DIAG_PP_CLOCK) || defined(MGX_DIAG_FWD_STAMPS) || defined(MGX_GEMM_A_AUX) || defined(MGX_GEMM_W_AUX) || defined(MGX_EPI_LAYOUT16)) &&       \
     !defined(MGX_DIAGNOSTIC_BUILD)

@@ -304,7 +304,14 @@ __device__ __forceinline__ uint32_t hi16(uint32_t a, uint32_t b) { return __buil
 __global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restrict__ in, bf16_raw* __restrict__ out,
                                                          float* __restrict__ part, int M, int N, RowMap im, long ldo) {
   __shared__ float cs[16][129];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // tx: 8-column group, ty: 8-row group
+  // tx: 8-column group, ty: 8-row group.  A wave covers 8 x 8 of them (64 columns x 64 rows), so that every load
+  // instruction of the wave reads 8 rows x 128 contiguous bytes and every store instruction writes 8 rows x 128 bytes
+  // (with 16 x 4 groups per wave the stores were 64-byte pieces of 16 different rows).  MGX_TR_MAP16X4: the old map (A/B).
+#ifdef MGX_TR_MAP16X4
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#else
+  const int tx = (threadIdx.x & 7) | (((threadIdx.x >> 6) & 1) << 3), ty = ((threadIdx.x >> 3) & 7) | ((threadIdx.x >> 7) << 3);
+#endif
   const int n0 = blockIdx.x * 128 + tx * 8;
   const long m0 = (long)blockIdx.y * 128 + ty * 8;
   uint32_t r[8][4];
