@@ -167,3 +167,26 @@ def test_round1_kernel_stays_selectable():
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "OK" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("M,N,K", [(36864, 3072, 3072), (8192 + 256 * 3, 3072, 15360), (32768, 9216, 3072)])
+def test_gemm_every_element_exact_on_integer_operands(M, N, K):
+    """The ping-pong K-loop's LDS hazards (DMA stage reuse, the half-a-barrier lag of waves 4-7, the pipeline running on
+    across output tiles) are a matter of construction; this is the screen for it: operands whose products and partial sums
+    are exactly representable (multiples of 1/32 below 2^24 / 32), so EVERY output element of a FLUX-size GEMM has to equal
+    the fp32 reference bit for bit whatever the summation order -- several tiles per workgroup, 48 and 240 K-tiles, repeated
+    launches (a stage overwritten early or read late would show as a wrong element in some launch)."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = (torch.randint(-4, 5, (M, K), generator=g, device="cuda").float() / 8).bfloat16()
+    W = (torch.randint(-2, 3, (N, K), generator=g, device="cuda").float() / 4).bfloat16()
+    ref = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    for r0 in range(0, M, 8192):                                   # reference in row blocks (fp32 copies of A are large)
+        ref[r0:r0 + 8192] = A[r0:r0 + 8192].float() @ W.float().t()
+    C = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    for _ in range(4):
+        C.fill_(float("nan"))
+        ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_F32_ACC, beta=0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(C, ref)
