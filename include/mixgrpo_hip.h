@@ -224,6 +224,12 @@ int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
 /* y = scale * float(x) (n % 8 == 0).  With mgx_cast_f32_bf16: the bf16 gradient buckets of the data-parallel all-reduce
  * (the reference's FSDP reduce-scatters its gradients per wrapped block, fastvideo/utils/fsdp_util.py:56-66) */
 int mgx_cast_bf16_f32(const uint16_t* x, float* y, long n, float scale, void* stream);
+/* y[m][0..N) = bf16(gelu_tanh(float(x[m][0..N)))), rows ldx / ldy elements apart (N, ldx, ldy % 8 == 0, 16-byte aligned):
+ * the activation of diffusers' FeedForward(activation_fn="gelu-approximate") / FLUX single block `act_mlp` re-created from a
+ * KEPT pre-activation, bit-identical to what mgx_gemm_bf16's bias+GELU epilogue writes (it applies GELU to the bf16-rounded
+ * Linear output); used by the activation-recompute pass the reference gets from torch.utils.checkpoint
+ * (fastvideo/utils/fsdp_util.py:26-66) to skip a GEMM whose input it kept. */
+int mgx_gelu_bf16(const uint16_t* x, long ldx, uint16_t* y, long ldy, long M, int N, void* stream);
 /* Backward of x + gate*y: dy = bf16(gate[b]*dout), dgate[b,:] = sum_rows dout*y (bf16) */
 long mgx_gate_bwd_workspace(long batches, long rows_per_batch, int D);
 int mgx_gate_bwd(const uint16_t* dout, long ldd, long d_bstride, const uint16_t* y, long ldy, const uint16_t* gate,

@@ -1249,6 +1249,25 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   return MGX_OK;
 }
 
+// y = bf16(gelu_tanh(float(x))) row by row: exactly what the bias+GELU epilogue writes as C from the pre-activation it
+// writes as aux (the epilogue applies GELU to the bf16-ROUNDED Linear output), so a training pass that KEPT the pre-activation
+// re-creates the activation without re-running the GEMM (mixgrpo_amd/flux_backward.py, `_Train.keep[...]["hid_pre"]`;
+// tests/test_hip_gemm.py holds the two to bit-identity on every bf16 value).
+__global__ void __launch_bounds__(256) gelu_rows_kernel(const bf16_raw* __restrict__ x, long ldx, bf16_raw* __restrict__ y,
+                                                        long ldy, long M, int N8) {
+  const long total = M * N8;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const long m = id / N8;
+    const int c = (int)(id - m * N8);
+    const uint4 u = *reinterpret_cast<const uint4*>(x + m * ldx + c * 8);
+    float v[8];
+    unpack8(u, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+    *reinterpret_cast<uint4*>(y + m * ldy + c * 8) = pack8(v);
+  }
+}
+
 }  // namespace
 
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
@@ -1314,6 +1333,17 @@ extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* cols
     transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
     if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
   }
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_gelu_bf16(const uint16_t* x, long ldx, uint16_t* y, long ldy, long M, int N, void* stream) {
+  MGX_REQUIRE(x && y && M > 0 && N > 0, "bad argument");
+  MGX_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0),
+              "rows must be 16-byte addressable");
+  const long total = M * (N / 8);
+  const int grid = (int)((total + 255) / 256 < 256L * 32 ? (total + 255) / 256 : 256L * 32);
+  gelu_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, M, N / 8);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

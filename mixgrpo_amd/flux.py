@@ -314,6 +314,27 @@ class FluxTransformer2DModel(torch.nn.Module):
         g.mul_(coef)
         return total.squeeze(0)
 
+    def grow_ff_keep(self, reserve_gib=None):
+        """Spend the device memory that is still free (beyond a reserve) on kept FF pre-activations, so that the training
+        pass's recompute skips those blocks' d -> 4d GEMM (flux_backward.KEEP_FF = "auto").  Called by `train_one_step` at
+        the start of its second step, when the first has shown the step's real peak.  Returns the number of blocks kept."""
+        from . import flux_backward as FB
+        if FB.KEEP_FF != "auto" or not FB.KEEP_ACTS:
+            return self.ff_blocks_kept()
+        reserve = (FB.KEEP_FF_RESERVE_GIB if reserve_gib is None else reserve_gib) * 2.0 ** 30
+        for base in self._work.values():
+            tr = base.train
+            if tr is None or tr.keep is None:
+                continue
+            free, _total = torch.cuda.mem_get_info(self.store.device)
+            n = int((free - reserve) // tr.ff_block_bytes())
+            if n > 0:
+                tr.grow_ff(tr.ff_kept() + n)
+        return self.ff_blocks_kept()
+
+    def ff_blocks_kept(self):
+        return sum(b.train.ff_kept() for b in self._work.values() if b.train is not None and b.train.keep is not None)
+
     # ------------------------------------------------------------------ forward
     def _workspace(self, B, L, N):
         """Workspace view for batch B of the (L, N) shape; the base grows to the largest batch seen."""
@@ -459,8 +480,14 @@ class FluxTransformer2DModel(torch.nn.Module):
                 if xm is not None:
                     (xm[:, :w.L] if name == "txt" else xm[:, w.L:]).copy_(w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
             ops.ln_modulate(xs_mid, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
-            ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
-                     Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
+            ff_kept = keep is not None and "hid_pre" in keep
+            if replay and ff_kept:                                           # pre-activation kept (`save["hid_pre"]` IS the
+                ops.gelu_rows(hpre, 4 * d, hid, 4 * d, M, 4 * d)             # kept buffer): GELU re-applied, no GEMM
+            else:
+                if hpre is None and ff_kept:
+                    hpre = keep["hid_pre"][sl]
+                ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
+                         Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
             if not replay:                                                   # y_ff saved: no ff.net.2 GEMM in the recompute
                 ops.gemm(Rows.of(hid), self.W(f"{p}.{ffn}.net.2.weight"), self.W(f"{p}.{ffn}.net.2.bias"), Xs, d, 4 * d,
                          EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
@@ -484,9 +511,13 @@ class FluxTransformer2DModel(torch.nn.Module):
                  self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(w.qkv), 3 * d, d)
         cat2 = w.cat.view(M, 5 * d)
         # the pre-activation (when kept) goes to columns 3d..7d of the [M, 7d] gradient staging buffer's twin
-        ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
-                 Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
-                 aux=None if save is None else save["hid_pre"])
+        ff_kept = keep is not None and "hid_pre" in keep
+        if replay and ff_kept:                       # pre-activation kept by the forward (`save["hid_pre"]` IS that buffer)
+            ops.gelu_rows(save["hid_pre"], 4 * d, cat2[0, d:], 5 * d, M, 4 * d)
+        else:
+            ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
+                     Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
+                     aux=save["hid_pre"] if save is not None else (keep["hid_pre"] if ff_kept else None))
         ops.qk_norm_rope(w.qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
                          w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))

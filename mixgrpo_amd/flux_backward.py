@@ -19,6 +19,13 @@ from .ops import BF16, F32, Rows, EPI_BIAS, EPI_BIAS_GATE_RES, EPI_DGELU, EPI_F3
 import os
 
 KEEP_ACTS = os.environ.get("MGX_KEEP_ACTS", "1") != "0"
+# How many blocks ALSO keep their FF / proj_mlp pre-activation ([M, 4d] bf16 per block: 0.79 GB at micro-batch 7), so that the
+# recompute pass re-creates the activation with an elementwise GELU instead of re-running the d -> 4d GEMM (1/3 of a block's
+# linear FLOPs).  An integer = that many leading blocks from the start; "auto" (default) = none until the trainer, at the
+# start of its SECOND train step (the first one has shown the step's real peak), hands out what the device still has free
+# beyond `KEEP_FF_RESERVE_GIB` (`FluxTransformer2DModel.grow_ff_keep`).  Values kept are the very values a recompute produces.
+KEEP_FF = os.environ.get("MGX_KEEP_FF_BLOCKS", "auto")
+KEEP_FF_RESERVE_GIB = float(os.environ.get("MGX_KEEP_FF_RESERVE_GIB", "12"))
 
 
 def _pad64(n):
@@ -51,6 +58,9 @@ class _Train:
                 if b < cfg.num_layers:
                     k.update(y_ff=e(M, d), x_mid=e(B, S, d))
                 self.keep.append(k)
+            self._ff_shape, self._ff_device = (M, 4 * d), device
+            if KEEP_FF != "auto":
+                self.grow_ff(int(KEEP_FF))
         self.save = dict(nrm1=e(M, d), nrm2=e(M, d), y_attn=e(M, d), y_ff=e(M, d), hid_pre=e(M, 4 * d),
                          x_mid=e(B, S, d), V=e(B, H, S, hd), Qt=z(B, H, hd, Sp), Kt=z(B, H, hd, Sp))
         self.dX = e(B, S, d)
@@ -70,6 +80,21 @@ class _Train:
     def view(self, B):
         return self if B == self.B else _TrainView(self, B)
 
+    def ff_block_bytes(self):
+        return self._ff_shape[0] * self._ff_shape[1] * 2
+
+    def ff_kept(self):
+        return sum(1 for k in (self.keep or []) if "hid_pre" in k)
+
+    def grow_ff(self, n_total):
+        """Keep the FF pre-activation of the first `n_total` blocks (allocates the missing buffers)."""
+        if self.keep is None:
+            return 0
+        for k in self.keep[:max(0, n_total)]:
+            if "hid_pre" not in k:
+                k["hid_pre"] = torch.empty(*self._ff_shape, dtype=BF16, device=self._ff_device)
+        return self.ff_kept()
+
 
 class _TrainView:
     """The first B batches of a `_Train` (batch-major contiguous buffers: plain prefixes; flat operand buffers shared)."""
@@ -84,7 +109,8 @@ class _TrainView:
         self.save = {k: (v[:M] if k in rows else v[:B]) for k, v in base.save.items()}
         self.keep = None
         if base.keep is not None:
-            self.keep = [{k: (v[:M] if k in ("y_attn", "y_ff") else v[:B]) for k, v in kb.items()} for kb in base.keep]
+            self.keep = [{k: (v[:M] if k in ("y_attn", "y_ff", "hid_pre") else v[:B]) for k, v in kb.items()}
+                         for kb in base.keep]
         self.dX, self.dO, self.dQ, self.dK, self.dV, self.dOt, self.delta = (
             t[:B] for t in (base.dX, base.dO, base.dQ, base.dK, base.dV, base.dOt, base.delta))
         self.dy, self.dbig, self.dnrm = base.dy[:M], base.dbig[:M], base.dnrm[:M]
@@ -234,6 +260,8 @@ def _backward(model, w, tr, sv, dout):
         m = sv["mods"][blk]
         kept = tr.keep[blk] if tr.keep else None
         save = dict(save0, y_attn=kept["y_attn"]) if kept else save0
+        if kept and "hid_pre" in kept:
+            save["hid_pre"] = kept["hid_pre"]                   # kept by the forward: the replay skips proj_mlp
         if kept is None:
             w.X.copy_(tr.block_in[blk])                        # full recompute rewrites the residual stream
         model._single_block(i, w, st_, cos, sin, save=save, mod_in=m, keep=kept, replay=kept is not None,
@@ -280,6 +308,8 @@ def _backward(model, w, tr, sv, dout):
         mods = sv["mods"][i]
         kept = tr.keep[i] if tr.keep else None
         save = dict(save0, y_attn=kept["y_attn"], y_ff=kept["y_ff"], x_mid=kept["x_mid"]) if kept else save0
+        if kept and "hid_pre" in kept:
+            save["hid_pre"] = kept["hid_pre"]                   # kept by the forward: the replay skips ff.net.0
         if kept is None:
             w.X.copy_(tr.block_in[i])                          # full recompute rewrites the residual stream
         model._double_block(i, w, st_, cos, sin, save=save, mods_in=mods, keep=kept, replay=kept is not None,

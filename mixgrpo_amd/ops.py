@@ -144,6 +144,12 @@ def cast_bf16(x, y):
     check(lib().mgx_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()))
 
 
+def gelu_rows(x, ldx, y, ldy, M, N):
+    """y[m, :N] = bf16(gelu_tanh(x[m, :N])) for M rows `ldx` / `ldy` elements apart: the bias+GELU epilogue's activation
+    re-created from a kept pre-activation (bit-identical, see include/mixgrpo_hip.h)."""
+    check(lib().mgx_gelu_bf16(ptr(x), ldx, ptr(y), ldy, M, N, stream()))
+
+
 def cast_f32(x, y, scale=1.0):
     """y (fp32) = scale * x (bf16)."""
     check(lib().mgx_cast_bf16_f32(ptr(x), ptr(y), x.numel(), float(scale), stream()))

@@ -215,6 +215,11 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
     """One GRPO train step (reference train_grpo_flux.py:341-624).  Returns (total_loss, grad_norm,
     policy_total_loss, kl_total_loss, total_clip_frac, gathered_reward_res)."""
     optimizer.zero_grad()
+    # second step on: the first step has shown the step's real memory peak; what the device still has free goes to kept FF
+    # pre-activations (fewer GEMMs in the recompute pass, identical values: flux_backward.KEEP_FF)
+    steps_done = getattr(transformer, "_mgx_train_steps", 0)
+    if steps_done == 1 and hasattr(transformer, "grow_ff_keep"):
+        transformer.grow_ff_keep()
     encoder_hidden_states, pooled_prompt_embeds, text_ids, caption = next(loader)
     encoder_hidden_states = encoder_hidden_states.to(device)
     pooled_prompt_embeds = pooled_prompt_embeds.to(device)
@@ -322,6 +327,10 @@ def train_one_step(args, device, transformer, vae, reward_function, optimizer, l
         rres = {k: v.mean().item() for k, v in gathered.items()}
     else:
         rres = gathered.mean().item()
+    try:
+        transformer._mgx_train_steps = steps_done + 1
+    except Exception:                                           # (a transformer object that refuses attributes)
+        pass
     return vals[0], (grad_norm.item() if grad_norm is not None else None), vals[1], vals[2], vals[3], rres
 
 

@@ -107,3 +107,55 @@ def test_train_step_with_mmdit_vs_oracle(tag, over, window):
     assert rp[0] == pytest.approx(ro[0], rel=0.05)          # logged loss (measured 1.2 % apart)
     assert rp[1] == pytest.approx(ro[1], rel=0.05)          # grad norm of the last update (measured 0.4 % apart)
     assert rp[4] == ro[4]                                   # same pairs clipped
+
+
+def test_second_step_spends_free_memory_on_kept_ff_activations(monkeypatch):
+    """`flux_backward.KEEP_FF = "auto"`: from the second train step on, device memory that the first step left free holds
+    the FF / proj_mlp pre-activations of as many blocks as fit, and the recompute pass re-creates those activations with an
+    elementwise GELU instead of the d -> 4d GEMM.  Same values by construction: two train steps must end in bit-identical
+    weights, losses and gradient norms with and without it."""
+    from mixgrpo_amd import flux_backward as FB
+    from mixgrpo_amd import train_grpo_flux as TG
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    from mixgrpo_amd.optim import FusedAdamW
+    dev = torch.device("cuda", 0)
+    a = Namespace(w=128, h=128, t=1, sampling_steps=6, shift=3.0, init_same_noise=True, training_strategy="part",
+                  output_dir="/tmp/x", experiment_name="t", reward_model="toy", multi_reward_mix="advantage_aggr",
+                  use_group=True, num_generations=4, trimmed_ratio=0.0, advantage_rerange_strategy="null", clip_range=1e-4,
+                  adv_clip_max=5.0, kl_coeff=0.0, gradient_accumulation_steps=2, frozen_init_timesteps=-1,
+                  timestep_fraction=1.0, dpm_algorithm_type="null", dpm_apply_strategy="post", dpm_post_compress_ratio=0.4,
+                  dpm_solver_order=2, dpm_solver_type="midpoint", sample_strategy="progressive", flow_grpo_sampling=True,
+                  eta=0.7, drop_last_sample=False, rollout_batch=0, train_microbatch=3)
+    G, T = a.num_generations, a.sampling_steps
+    N = (a.h // 16) * (a.w // 16)
+    g = torch.Generator().manual_seed(11)
+    inj = {"x_T": torch.randn(1, 16, a.h // 8, a.w // 8, generator=g).bfloat16(),
+           "steps": [torch.randn(G, N, 64, generator=g).bfloat16() for _ in range(T)]}
+    batch = ((0.5 * torch.randn(1, 8, 64, generator=g)).bfloat16().to(dev), torch.randn(1, 32, generator=g).bfloat16().to(dev),
+             torch.zeros(1, 3).to(dev), ["p"])
+    rewards = [0.1, 0.9, 0.3, 0.6]
+    P = OM.init_params(OM.FluxConfig(**KW), seed=3, std=0.05, bias_std=0.02)
+
+    def reward(latents, captions):
+        n = latents.shape[0]
+        return [rewards[i] for i in range(n)], {"A": [rewards[i] for i in range(n)]}
+
+    runs = []
+    for keep_ff in ("0", "auto"):
+        monkeypatch.setattr(FB, "KEEP_FF", keep_ff)
+        monkeypatch.setattr(FB, "KEEP_FF_RESERVE_GIB", 0.0)
+        m = FluxTransformer2DModel(FluxConfig(**KW), device=dev)
+        m.load_state_dict({k: t.to(dev) for k, t in P.items()})
+        opt = FusedAdamW(m, lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+        ap = copy.copy(a)
+        ap.injected_noise = inj
+        res, kept = [], []
+        for step in range(2):
+            res.append(TG.train_one_step(ap, dev, m, None, reward, opt, _Sched(), iter([batch]), None, 1.0, [1, 2], step,
+                                         {"A": 1.0}))
+            kept.append(m.ff_blocks_kept())
+        runs.append((res, kept, m.store.w32.clone() if hasattr(m.store, "w32") else m.flat_param.detach().clone()))
+    assert runs[0][1] == [0, 0]
+    assert runs[1][1] == [0, 2]                           # nothing in the first step, both blocks from the second on
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][2], runs[1][2])

@@ -190,3 +190,32 @@ def test_gemm_every_element_exact_on_integer_operands(M, N, K):
         ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_F32_ACC, beta=0.0)
         torch.cuda.synchronize()
         assert torch.equal(C, ref)
+
+
+@pytest.mark.parametrize("N", [256, 64])          # 256: the persistent 256x256 kernel's register epilogue; 64: the 128x128 kernel's
+def test_gelu_rows_is_the_gemm_epilogue_on_every_bf16_value(N):
+    """`mgx_gelu_bf16` re-creates the bias+GELU epilogue's activation from a kept pre-activation (the recompute pass then
+    skips the GEMM): the two have to agree BIT FOR BIT.  Exhaustive: a GEMM whose Linear output is exactly the value v
+    (A[m][0] = v, W[n][0] = 1, everything else 0) for all 65536 bf16 patterns."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    M, K = 65536, 128
+    vals = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16).cuda()
+    finite = torch.isfinite(vals.float())
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    A[:, 0] = torch.where(finite, vals, torch.zeros_like(vals))               # (inf * 0 would poison the row)
+    W = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
+    W[:, 0] = 1.0
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_GELU, aux=pre)
+    assert torch.equal(pre[:, 0].view(torch.int16), A[:, 0].view(torch.int16)) or torch.equal(pre[:, 0].float(), A[:, 0].float())
+    out = torch.full((M, N + 8), 3.0, dtype=torch.bfloat16, device="cuda")    # strided destination (the single block's cat)
+    ops.gelu_rows(pre, N, out, N + 8, M, N)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :N].view(torch.int16), C.view(torch.int16))     # bit for bit, every value, every column
+    assert (out[:, N:] == 3.0).all()
+    x = A[:, 0].float()
+    big = x.abs() > 1e-30                                                     # (bf16 subnormals halve with a visible rounding)
+    # (sanity against torch: its tanh saturates to exactly -1 below x ~ -5.5 where the true value is still ~ -1e-8)
+    assert torch.allclose(C[:, 0].float()[big], torch.nn.functional.gelu(x[big], approximate="tanh"), rtol=2.0 ** -7, atol=1e-6)

@@ -172,8 +172,11 @@ def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
     values a recompute would produce, so the gradients must be bit-identical to full block recompute."""
     from mixgrpo_amd import flux_backward as FB
     grads = []
-    for keep in (True, False):
+    # (True, "3"): additionally the FF pre-activation of the first three blocks (two double + one single) is kept and their
+    # d -> 4d GEMM is replaced by an elementwise GELU in the recompute (FB.KEEP_FF)
+    for keep, keep_ff in ((True, "0"), (False, "0"), (True, "3"), (True, "99")):
         monkeypatch.setattr(FB, "KEEP_ACTS", keep)
+        monkeypatch.setattr(FB, "KEEP_FF", keep_ff)
         ocfg, P, m = build_pair(small_cfg(2, 2))
         x, ehs, pooled, ids, tids, t, gd = make_inputs(2, 6, 10, 24, seed=3)
         R = torch.randn(2, 60, 64, generator=torch.Generator().manual_seed(9)).cuda()
@@ -182,9 +185,12 @@ def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
         (out.float() * R).sum().backward()
         w = next(iter(m._work.values()))
         assert (w.train.keep is not None) == keep
+        if keep:
+            assert w.train.ff_kept() == min(int(keep_ff), 4)
         grads.append((out.detach().clone(), m.store.g32.clone()))
-    assert torch.equal(grads[0][0], grads[1][0])
-    assert torch.equal(grads[0][1], grads[1][1])
+    for other in grads[1:]:
+        assert torch.equal(grads[0][0], other[0])
+        assert torch.equal(grads[0][1], other[1])
 
 
 def test_attention_backward_vs_torch():
