@@ -42,10 +42,20 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _generate():
+    """Rewrite the generated instruction streams (csrc/gen/*.py -> csrc/*_body.inc); files are only touched on change."""
+    sys.path.insert(0, os.path.join(CSRC, "gen"))
+    try:
+        import attn_fwd64
+        attn_fwd64.write()
+    finally:
+        sys.path.pop(0)
+
+
 def _digest(path, flags):
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
-    for p in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+    for p in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + \
             [os.path.join(HERE, "..", "include", "mixgrpo_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
@@ -65,6 +75,7 @@ def build(force=False, verbose=True, diagnostic_out=None, diagnostic_flags=()):
     elif diagnostic_flags:
         raise RuntimeError("extra compile flags are only accepted for a diagnostic build (diagnostic_out=...)")
     os.makedirs(obj_dir, exist_ok=True)
+    _generate()
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in _sources():

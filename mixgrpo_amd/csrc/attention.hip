@@ -356,6 +356,40 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 64-query waves
+// attn_fwd64_kernel: 4 waves x 64 queries (two 32-query chains that share every K / V^T fragment), one wave per SIMD with
+// all 512 registers, K / V^T tiles by LDS-DMA.  The body is a generated, hand-placed instruction stream: design, register
+// map and schedule in csrc/gen/attn_fwd64.py; checked on the CPU by tests/asm_emu.py (interpreter + hazard pass) before it
+// runs here.  Needs S % 256 == 0 (FLUX: 512 + 4096 tokens); other shapes take attn_fwd_kernel above.
+#include "attn_fwd64_body.inc"
+
+__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(AttnArgs g) {
+  const int nq = g.S >> 8;
+  const int nwg = nq * g.H * g.B;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int qt = bid % nq;
+  const int bh = bid / nq;
+  const int b = bh / g.H, hh = bh - b * g.H;
+  const unsigned long long qp = (unsigned long long)(g.Q + ((long)bh * g.S + qt * 256) * HD);
+  const unsigned long long kp = (unsigned long long)(g.K + (long)bh * g.S * HD);
+  const unsigned long long vp = (unsigned long long)(g.Vt + (long)bh * HD * g.Sp);
+  const unsigned long long op = (unsigned long long)(g.O + (long)b * g.o_bstride + (long)(qt * 256) * g.ldo + hh * HD);
+  const unsigned long long lp = g.lse ? (unsigned long long)(g.lse + (long)bh * g.S + qt * 256) : 0ull;
+  const int ntiles = g.S >> 6;
+  asm volatile(ATTN_FWD64_BODY
+               :
+               : [tid] "v"(threadIdx.x), [q_lo] "s"((unsigned)qp), [q_hi] "s"((unsigned)(qp >> 32)), [k_lo] "s"((unsigned)kp),
+                 [k_hi] "s"((unsigned)(kp >> 32)), [v_lo] "s"((unsigned)vp), [v_hi] "s"((unsigned)(vp >> 32)),
+                 [o_lo] "s"((unsigned)op), [o_hi] "s"((unsigned)(op >> 32)), [l_lo] "s"((unsigned)lp),
+                 [l_hi] "s"((unsigned)(lp >> 32)), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e),
+                 [nloop] "s"((ntiles - 2) >> 1), [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128)
+               : ATTN_FWD64_CLOBBERS);
+}
+
 }  // namespace
 
 extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
@@ -373,6 +407,18 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   const int lds = 2 * (K_TILE_BYTES + V_TILE_BYTES);
   hipStream_t st = (hipStream_t)stream;
   static const int ovl = getenv("MGX_ATTN_OVL") ? atoi(getenv("MGX_ATTN_OVL")) : 1;
+  const char* w64e = getenv("MGX_ATTN_W64");   // read per call: tests switch kernels inside one process
+  const int w64 = w64e ? atoi(w64e) : 1;
+  if (w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      attr = true;
+    }
+    attn_fwd64_kernel<<<(S / 256) * H * B, 256, 65536, st>>>(g);
+    MGX_CHECK_LAUNCH();
+    return MGX_OK;
+  }
   if (nw == 8 && defer && ovl) attn_fwd_kernel<8, true, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (nw == 8 && defer) attn_fwd_kernel<8, true><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);
   else if (nw == 8) attn_fwd_kernel<8, false><<<cdiv(S, 256) * H * B, 512, lds, st>>>(g);

@@ -1,0 +1,108 @@
+"""The generated instruction stream of attn_fwd64_kernel (mixgrpo_amd/csrc/gen/attn_fwd64.py), checked WITHOUT a GPU:
+interpreted by tests/asm_emu.py (4 waves, LDS, LDS-DMA, waitcnt-delayed visibility) against an fp64 softmax(Q K^T) V of the
+same bf16 operands, plus the static pass over the software-managed gfx950 hazards.  The kernel replaces
+F.scaled_dot_product_attention at fastvideo/utils/sampling_utils.py:68-82 / fastvideo/train_grpo_flux.py:134-144."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "mixgrpo_amd", "csrc", "gen"))
+import asm_emu  # noqa: E402
+import attn_fwd64 as G  # noqa: E402
+
+
+def _bf16(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _f32(h):
+    return (h.astype(np.uint32) << 16).view(np.float32)
+
+
+def _emulate(S, mode, order, seed=0, spike=False, qt=0, with_lse=True):
+    rng = np.random.default_rng(seed)
+    q, k, v = (rng.standard_normal((S, 128)).astype(np.float32) for _ in range(3))
+    if spike:    # two keys that outscore their query's first-tile maximum by far more than 2^40: the rescale fix-up must run
+        k[200] = 8 * q[qt * 256 + 70]
+        k[S - 3] = 6 * q[qt * 256 + 100]
+    Q, K = _bf16(q), _bf16(k)
+    Vt = np.ascontiguousarray(_bf16(v).T)
+    ldo = 256                                   # two heads wide: this head's columns are 32..159 (byte offset 64)
+    O = np.zeros((S, ldo), np.uint16)
+    lse = np.full(S, -7.0, np.float32)
+    nt, scale = S // 64, 1 / math.sqrt(128)
+    inputs = dict(tid=np.arange(256).reshape(4, 64), q=("ptr", "Q", qt * 256 * 256), k=("ptr", "K", 0), v=("ptr", "V", 0),
+                  o=("ptr", "O", qt * 256 * ldo * 2 + 64), l=("ptr", "L", qt * 256 * 4), sp2=S * 2, ldo2=ldo * 2,
+                  cs=float(np.float32(scale * 1.4426950408889634)), nloop=(nt - 2) // 2, kmax=(nt - 1) * 16384,
+                  vmax=(nt - 1) * 128)
+    if not with_lse:
+        inputs["l"] = 0
+        inputs = {**{k_: v_ for k_, v_ in inputs.items() if k_ != "l"}, "l_lo": 0, "l_hi": 0}
+    m = asm_emu.Machine(G.generate(), inputs, dict(Q=Q, K=K, V=Vt, O=O, L=lse), mode=mode, order=order).run()
+    qf, kf, vf = (_f32(x).astype(np.float64) for x in (Q, K, _bf16(v)))
+    s = qf[qt * 256:qt * 256 + 256] @ kf.T * scale
+    mx = s.max(1, keepdims=True)
+    p = np.exp(s - mx)
+    ref = p @ vf / p.sum(1, keepdims=True)
+    got = _f32(O[qt * 256:qt * 256 + 256, 32:160]).astype(np.float64)
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    lse_err = np.abs(lse[qt * 256:qt * 256 + 256] - (mx[:, 0] + np.log(p.sum(1)))).max()
+    other = np.delete(O, np.s_[qt * 256:qt * 256 + 256], axis=0)
+    assert not other.any() and not O[:, :32].any() and not O[:, 160:].any(), "stores outside this workgroup's O block"
+    return rel, lse_err, lse, m
+
+
+def test_generated_file_is_current():
+    with open(G.OUT_BODY) as f:
+        assert f.read() == G.render(), "run `python mixgrpo_amd/csrc/gen/attn_fwd64.py` (or mixgrpo_amd.build)"
+
+
+def test_static_hazards_clean():
+    text = G.generate()
+    assert asm_emu.check_hazards(text) == []
+    # the loop body once more behind itself: hazards across the back edge
+    lines = text.split("\n")
+    lo = next(i for i, ln in enumerate(lines) if ln.startswith(".Lloop_"))
+    hi = next(i for i, ln in enumerate(lines) if ln.startswith(".Lloopdone_"))
+    assert asm_emu.check_hazards("\n".join(lines[lo + 1:hi] + lines[lo + 1:hi])) == []
+    assert text.count("v_mfma_f32_32x32x16_bf16") == 256
+
+
+def test_hazard_checker_sees_a_planted_hazard():
+    bad = "v_mfma_f32_32x32x16_bf16 v[4:19], a[0:3], a[4:7], 0\nv_add_f32 v40, v4, v5\n"
+    assert any(x.startswith("R1") for x in asm_emu.check_hazards(bad))
+    bad = "v_exp_f32 v1, v2\nv_add_f32 v3, v1, v1\n"
+    assert any(x.startswith("R3") for x in asm_emu.check_hazards(bad))
+    bad = "v_cvt_pk_bf16_f32 v68, v1, v2\nv_mfma_f32_32x32x16_bf16 a[0:15], v[100:103], v[68:71], a[0:15]\n"
+    assert any(x.startswith("R2") for x in asm_emu.check_hazards(bad))
+
+
+@pytest.mark.parametrize("mode,order", [("late", [0, 1, 2, 3]), ("early", [3, 2, 1, 0]), ("early", [0, 1, 2, 3])])
+def test_emulated_vs_reference_two_tiles_per_loop(mode, order):
+    rel, lse_err, _, m = _emulate(256, mode, order)              # 4 tiles: first, one loop trip, last
+    assert rel < 4e-3 and lse_err < 1e-5
+    assert m.mfma_count == 4 * 4 * 64
+    assert not any(k.startswith(".Lfix") for k in m.branches_taken)
+
+
+def test_emulated_second_query_block_and_longer_loop():
+    rel, lse_err, _, _ = _emulate(512, "late", [2, 0, 3, 1], seed=1, qt=1)
+    assert rel < 4e-3 and lse_err < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["late", "early"])
+def test_emulated_rescale_fixup_runs_and_is_right(mode):
+    rel, lse_err, _, m = _emulate(512, mode, [1, 3, 0, 2], seed=2, spike=True)
+    assert any(k.startswith(".Lfix") for k in m.branches_taken), "the spiked keys did not force the rescale path"
+    assert rel < 4e-3 and lse_err < 1e-4
+
+
+def test_emulated_null_lse_pointer_stores_nothing():
+    rel, _, lse, _ = _emulate(256, "late", [0, 1, 2, 3], seed=3, with_lse=False)
+    assert rel < 4e-3 and (lse == -7.0).all()

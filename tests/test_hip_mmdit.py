@@ -166,6 +166,59 @@ def test_attention_deferred_rescale_paths(growth):
     assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,S,ldo_mult", [(1, 1, 256, 1), (2, 3, 768, 5), (1, 24, 1536, 1)])
+def test_attention_fwd64_vs_torch_and_vs_the_8_wave_kernel(B, H, S, ldo_mult, monkeypatch):
+    """The 64-query-wave forward (S % 256 == 0: generated instruction stream, csrc/gen/attn_fwd64.py) against an fp32 torch
+    softmax(Q K^T / sqrt(d)) V, and against the 8-wave kernel on the same operands (MGX_ATTN_W64=0): same tolerance to the
+    reference, agreement between the two within bf16 rounding of O, columns beyond the head block untouched."""
+    from mixgrpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + H)
+    q, k, v = (torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16() for _ in range(3))
+    vt = v.transpose(-1, -2).contiguous()
+    ldo = H * 128 * ldo_mult
+    outs = []
+    for w64 in ("1", "0"):
+        monkeypatch.setenv("MGX_ATTN_W64", w64)
+        O = torch.zeros(B, S, ldo, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, S, device="cuda")
+        ops.attn_fwd(q, k, vt, O, lse, B, H, S, S, ldo, S * ldo, 1 / math.sqrt(128))
+        outs.append((O, lse))
+    s = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128)
+    ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, S, H * 128)
+    for O, lse in outs:
+        assert rel_err(O[:, :, :H * 128], ref) < 6e-3
+        assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+        assert not O[:, :, H * 128:].any()
+    assert rel_err(outs[0][0], outs[1][0].float()) < 4e-3
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
+
+
+def test_attention_fwd64_rescale_path():
+    """The 64-query-wave forward keeps the FIRST tile's row maximum and only rescales when a tile's row sum passes 2^40
+    (csrc/gen/attn_fwd64.py).  Keys that outscore their query's first-tile maximum by ~90 and ~65 nats force that rare
+    path (fp32 overflow of the tile's row sum -> fix-up) in a middle tile and in the last one; a query in each of the two
+    chains of a wave is hit.  Full-tensor fp32 reference (MI355X guide, rule 26)."""
+    from mixgrpo_amd import ops
+    B, H, S = 1, 2, 1024
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v = (torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16() for _ in range(3))
+    k[:, :, 200] = (8 * q[:, :, 70].float()).bfloat16()        # query 70: wave 1, chain A of the first query block
+    k[:, :, S - 3] = (6 * q[:, :, 100].float()).bfloat16()     # query 100: wave 1, chain B; last tile
+    k[:, :, 333] = (7 * q[:, :, 700].float()).bfloat16()       # third query block
+    O = torch.empty(B, S, H * 128, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device="cuda")
+    ops.attn_fwd(q, k, v.transpose(-1, -2).contiguous(), O, lse, B, H, S, S, H * 128, S * H * 128, 1 / math.sqrt(128))
+    s = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128)
+    ref = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, S, H * 128)
+    assert torch.isfinite(O.float()).all()
+    assert rel_err(O, ref) < 6e-3
+    got = O.view(B, S, H, 128).permute(0, 2, 1, 3)
+    refh = ref.view(B, S, H, 128).permute(0, 2, 1, 3)
+    for row in (70, 100, 700):                                  # the spiked rows themselves: O = the spiked key's V row
+        assert rel_err(got[:, :, row], refh[:, :, row]) < 6e-3
+    assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-3)
+
+
 def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
     """The training forward keeps the attention output / LSE and the pre-gate outputs of to_out, ff.net.2 and proj_out so
     that the recompute pass skips attention and those GEMMs (flux_backward._Train.keep).  The kept values are the very
