@@ -244,8 +244,10 @@ int mgx_sqnorm_f32(const float* g, long n, double* ws, float* out, float beta, v
 /* torch.optim.AdamW step (train_grpo_flux.py:715-721,607) on flat fp32 master weights, fused with the
  * clip-by-global-norm scaling (gnorm_sq: device pointer to sum g^2 of the UNSCALED grads, or NULL for no
  * clipping; grad_scale multiplies every gradient first, e.g. 1/world_size) and the bf16 compute-copy refresh. */
-int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, long n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm,
+/* lr, betas, eps and weight decay are DOUBLES, as the Python floats torch.optim.AdamW holds them: every derived coefficient
+ * (1 - beta2, lr / (1 - beta1^step), ...) is formed in double and rounded to fp32 once, like torch's foreach step does. */
+int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, long n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, int step, const float* gnorm_sq, float max_norm,
                    float grad_scale, void* stream);
 int mgx_scale_f32(float* x, long n, float s, void* stream);
 

@@ -36,6 +36,7 @@ _P = C.c_void_p
 _I = C.c_int
 _L = C.c_long
 _F = C.c_float
+_D = C.c_double
 
 # name -> (restype, argtypes); mirrors include/mixgrpo_hip.h one to one
 SIGNATURES = {
@@ -78,7 +79,7 @@ SIGNATURES = {
     "mgx_gate_bwd": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _P]),
     "mgx_sqnorm_workspace": (_L, []),
     "mgx_sqnorm_f32": (_I, [_P, _L, _P, _P, _F, _P]),
-    "mgx_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+    "mgx_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
     "mgx_scale_f32": (_I, [_P, _L, _F, _P]),
 }
 

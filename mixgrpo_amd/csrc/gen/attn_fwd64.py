@@ -58,6 +58,7 @@ QOFF_A, QOFF_B = 232, 233
 OOFF_A, OOFF_B = 234, 235
 LOFF = 236
 V_LAST = 239
+DBG_OFF, DBG_LO = 237, 238   # v237, v[238:239]: diagnostic builds only
 
 # scalars (copied from the asm operands into fixed registers, all clobbered)
 sW, sWOFF = 64, 65
@@ -68,6 +69,7 @@ sTMP = 73
 sQ, sK, sV, sO, sL = 74, 76, 78, 80, 82
 sSP2, sLDO2, sCS, sNLOOP, sKMAX, sVMAX = 84, 85, 86, 87, 88, 89
 sRET = 90                 # pair
+sDBG = 92                 # pair (diagnostic builds)
 S_FIRST, S_LAST = 64, 95
 
 K_BASE, V_BASE = 0, 32768
@@ -276,11 +278,20 @@ def fixup(A, ch, back):
     A.e(f"s_branch {back}")
 
 
+TIMING_ONLY = set()        # diagnostic variants (wrong results; scratch harness only): "nodma", "nolds", "novalu", "nobarrier"
+
+
 def segment(A, mfmas, valu_gaps, valu_tail, lds=None, dma=None, pre=None, waits=None):
     """Emit one segment: per gap [wait] MFMA, the gap's VALU slice, at most one LDS read, at most one DMA piece.
 
     lds: {gap: instr}; dma: {gap: (m0 write, load)}; waits: {gap: 's_waitcnt ...'} placed in front of the gap's MFMA."""
     lds, dma, waits = lds or {}, dma or {}, waits or {}
+    if "nodma" in TIMING_ONLY:
+        dma = {}
+    if "nolds" in TIMING_ONLY:
+        lds = {}
+    if "novalu" in TIMING_ONLY:
+        valu_gaps = [[] for _ in valu_gaps]
     for x in pre or []:
         A.e(x)
     for g, m in enumerate(mfmas):
@@ -342,7 +353,8 @@ def iteration(A, par, fixups, first=False, last=False):
     end_of_softmax(A, CB, fixups, first)
     if not last:
         A.e("s_waitcnt vmcnt(0)")                           # this iteration's K(i+2), V^T(i+1) pieces
-        A.e("s_barrier")
+        if "nobarrier" not in TIMING_ONLY:
+            A.e("s_barrier")
 
 
 def end_of_softmax(A, ch, fixups, first):
@@ -513,11 +525,32 @@ def epilogue(A):
     A.e("s_waitcnt vmcnt(0)")
 
 
-def generate():
+def stamp(A, k):
+    """Diagnostic builds only (scratch/fwd64_diag.hip): shader-clock stamp k of this wave into the debug buffer."""
+    A.e(f"s_memtime {sr(sRET, 2)}")
+    A.e("s_waitcnt lgkmcnt(0)")
+    A.e(f"v_mov_b32 {v(DBG_LO)}, {s(sRET)}")
+    A.e(f"v_mov_b32 {v(DBG_LO + 1)}, {s(sRET + 1)}")
+    A.e("s_mov_b64 exec, 1")
+    A.e(f"global_store_dwordx2 {v(DBG_OFF)}, {vr(DBG_LO, 2)}, {sr(sDBG, 2)} offset:{8 * k}")
+    A.e("s_mov_b64 exec, -1")
+
+
+def generate(diag=False):
     A = Asm()
     fixups = []
+    if diag:
+        A.e(f"s_mov_b32 {s(sDBG)}, %[d_lo]")
+        A.e(f"s_mov_b32 {s(sDBG + 1)}, %[d_hi]")
+        A.e(f"v_lshrrev_b32 {v(DBG_OFF)}, 6, %[tid]")
+        A.e(f"v_lshlrev_b32 {v(DBG_OFF)}, 6, {v(DBG_OFF)}")         # 64 bytes of stamps per wave
+        stamp(A, 0)
     prologue(A)
+    if diag:
+        stamp(A, 1)
     iteration(A, 0, fixups, first=True)
+    if diag:
+        stamp(A, 2)
     A.e(f"s_mov_b32 {s(sLOOP)}, {s(sNLOOP)}")
     loop, done = A.new_label("loop"), A.new_label("loopdone")
     A.e(f"s_cmp_eq_u32 {s(sLOOP)}, 0")
@@ -529,8 +562,22 @@ def generate():
     A.e(f"s_cmp_lg_u32 {s(sLOOP)}, 0")
     A.e(f"s_cbranch_scc1 {loop}")
     A.label(done)
+    if diag:
+        stamp(A, 3)
     iteration(A, 1, fixups, last=True)
+    if diag:
+        stamp(A, 4)
     epilogue(A)
+    if diag:
+        stamp(A, 5)
+        A.e(f"s_memrealtime {sr(sRET, 2)}")
+        A.e("s_waitcnt lgkmcnt(0)")
+        A.e(f"v_mov_b32 {v(DBG_LO)}, {s(sRET)}")
+        A.e(f"v_mov_b32 {v(DBG_LO + 1)}, {s(sRET + 1)}")
+        A.e("s_mov_b64 exec, 1")
+        A.e(f"global_store_dwordx2 {v(DBG_OFF)}, {vr(DBG_LO, 2)}, {sr(sDBG, 2)} offset:48")
+        A.e("s_mov_b64 exec, -1")
+        A.e("s_waitcnt vmcnt(0)")
     end = A.new_label("end")
     A.e(f"s_branch {end}")
     A.c("================ out-of-line rescale fix-ups")
@@ -551,10 +598,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_BODY = os.path.join(HERE, "..", "attn_fwd64_body.inc")
 
 
-def render():
-    body = generate()
+def render(diag=False):
+    body = generate(diag)
     lines = ["// GENERATED by mixgrpo_amd/csrc/gen/attn_fwd64.py -- do not edit; see that file for the design.",
-             "#define ATTN_FWD64_CLOBBERS " + clobbers(), "static const char* const kAttnFwd64Sentinel = \"attn_fwd64\";",
+             "#define ATTN_FWD64_CLOBBERS " + clobbers(),
              "#define ATTN_FWD64_BODY \\"]
     for ln in body.rstrip("\n").split("\n"):
         lines.append('  "' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n" \\')
@@ -573,6 +620,14 @@ def write(path=OUT_BODY):
 
 if __name__ == "__main__":
     if "--print" in sys.argv:
-        sys.stdout.write(generate())
+        sys.stdout.write(generate("--diag" in sys.argv))
+    elif "--diag" in sys.argv:                      # scratch/fwd64_diag.hip includes this one
+        for a_ in sys.argv:
+            if a_.startswith("--timing-only="):
+                TIMING_ONLY.update(a_.split("=")[1].split(","))
+        out = os.path.join(HERE, "..", "..", "..", "scratch", "attn_fwd64_diag_body.inc")
+        with open(out, "w") as f:
+            f.write(render(diag=True))
+        print(out)
     else:
         print(write())

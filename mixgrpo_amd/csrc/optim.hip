@@ -5,6 +5,8 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <cmath>
+
 namespace {
 
 __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
@@ -34,8 +36,17 @@ __global__ void sqnorm_finish_kernel(const double* __restrict__ part, int nb, fl
   if (threadIdx.x == 0) out[0] = beta * out[0] + (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+// Scalar coefficients exactly as torch.optim.AdamW's (foreach) step forms them: in Python DOUBLE precision on the host, then
+// one rounding to fp32 where the elementwise op takes them (1 - beta2 = 0.0010000000000000009 -> 0.001f, NOT 1.0f - 0.999f =
+// 0.00099998713, which is 1.3e-5 off in the second moment).
 struct AdamArgs {
-  float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, max_norm;
+  float decay;       // 1 - lr * weight_decay             (_foreach_mul_(params, ...))
+  float omb1;        // 1 - beta1                         (_foreach_lerp_(exp_avgs, grads, ...))
+  float beta2, omb2; // beta2, 1 - beta2                  (_foreach_mul_, _foreach_addcmul_)
+  float bc2_sqrt;    // sqrt(1 - beta2^step)              (_foreach_div_(sqrt(exp_avg_sq), ...))
+  float eps;
+  float step_size;   // lr / (1 - beta1^step)             (_foreach_addcdiv_(params, exp_avgs, denom, -step_size))
+  float max_norm;
 };
 
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ w, bf16_raw* __restrict__ w16,
@@ -60,11 +71,12 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ w, bf16_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gr = fg[j] * clip;
-      fw[j] = fw[j] * (1.0f - a.lr * a.wd);
-      fm[j] = a.beta1 * fm[j] + (1.0f - a.beta1) * gr;
-      fv[j] = a.beta2 * fv[j] + (1.0f - a.beta2) * gr * gr;
+      fw[j] = fw[j] * a.decay;
+      fm[j] = fm[j] + a.omb1 * (gr - fm[j]);                    // lerp, weight < 0.5
+      fv[j] = fv[j] * a.beta2;
+      fv[j] = fv[j] + a.omb2 * gr * gr;
       const float denom = sqrtf(fv[j]) / a.bc2_sqrt + a.eps;
-      fw[j] = fw[j] - (a.lr / a.bc1) * (fm[j] / denom);
+      fw[j] = fw[j] - a.step_size * (fm[j] / denom);
     }
     *reinterpret_cast<float4*>(w + i) = pw;
     *reinterpret_cast<float4*>(m + i) = pm;
@@ -101,15 +113,19 @@ extern "C" int mgx_sqnorm_f32(const float* g, long n, double* ws, float* out, fl
   return MGX_OK;
 }
 
-extern "C" int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, long n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, const float* gnorm_sq,
+extern "C" int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, long n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int step, const float* gnorm_sq,
                               float max_norm, float grad_scale, void* stream) {
   MGX_REQUIRE(w && w16 && g && m && v && n > 0 && step >= 1, "bad argument");
   MGX_REQUIRE(n % 4 == 0, "parameter count must be padded to a multiple of 4");
   AdamArgs a;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-  a.bc1 = 1.0f - powf(beta1, (float)step);
-  a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.omb1 = (float)(1.0 - beta1);
+  a.beta2 = (float)beta2;
+  a.omb2 = (float)(1.0 - beta2);
+  a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  a.eps = (float)eps;
+  a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   a.max_norm = max_norm;
   int nb = cdiv(n, 1024 * 4);
   if (nb > 8192) nb = 8192;

@@ -402,6 +402,12 @@ class Machine:
     def i_s_nop(self, w, ins, o):
         pass
 
+    def i_s_memtime(self, w, ins, o):
+        r = reg_range(o[0])
+        w.s[r[1]], w.s[r[1] + 1] = w.icount & 0xFFFFFFFF, 0
+
+    i_s_memrealtime = i_s_memtime
+
     def i_s_setprio(self, w, ins, o):
         pass
 
