@@ -509,6 +509,42 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(BwdArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ, 64-query waves
+// attn_bwd_dq64_kernel: 4 waves x 64 queries (two 32-query chains sharing every K / V / K^T fragment), one wave per SIMD, a
+// generated hand-placed instruction stream: csrc/gen/attn_bwd_dq64.py (design, register map, schedule), checked on the CPU by
+// tests/test_attn_bwd64_emulated.py.  S % 256 == 0; other shapes take attn_bwd_dq_kernel above.
+#include "attn_bwd_dq64_body.inc"
+
+__global__ void __launch_bounds__(256, 1) attn_bwd_dq64_kernel(BwdArgs g) {
+  const int nq = g.S >> 8;
+  int bid = blockIdx.x;
+  xcd_remap(bid, nq * g.H * g.B);
+  const int qt = bid % nq, bh = bid / nq;
+  const int b = bh / g.H, hh = bh - b * g.H;
+  const long bhS = (long)bh * g.S;
+  const unsigned long long qp = (unsigned long long)(g.Q + (bhS + qt * 256) * HD);
+  const unsigned long long kp = (unsigned long long)(g.K + bhS * HD);
+  const unsigned long long vp = (unsigned long long)(g.V + bhS * HD);
+  const unsigned long long ktp = (unsigned long long)(g.Kt + (long)bh * HD * g.Sp);
+  const unsigned long long dop = (unsigned long long)(g.dO + (long)b * g.o_bstride + (long)(qt * 256) * g.ldo + hh * HD);
+  const unsigned long long lsep = (unsigned long long)(g.lse + bhS + qt * 256);
+  const unsigned long long dlp = (unsigned long long)(g.delta + bhS + qt * 256);
+  const unsigned long long dqp = (unsigned long long)(g.dQ + (bhS + qt * 256) * HD);
+  const int ntiles = g.S >> 6;
+#define LOHI(x) "s"((unsigned)(x)), "s"((unsigned)((x) >> 32))
+  asm volatile(ATTN_BWD_DQ64_BODY
+               :
+               : [tid] "v"(threadIdx.x), [q_lo] "s"((unsigned)qp), [q_hi] "s"((unsigned)(qp >> 32)), [k_lo] "s"((unsigned)kp),
+                 [k_hi] "s"((unsigned)(kp >> 32)), [v_lo] "s"((unsigned)vp), [v_hi] "s"((unsigned)(vp >> 32)),
+                 [kt_lo] "s"((unsigned)ktp), [kt_hi] "s"((unsigned)(ktp >> 32)), [do_lo] "s"((unsigned)dop),
+                 [do_hi] "s"((unsigned)(dop >> 32)), [lse_lo] "s"((unsigned)lsep), [lse_hi] "s"((unsigned)(lsep >> 32)),
+                 [dl_lo] "s"((unsigned)dlp), [dl_hi] "s"((unsigned)(dlp >> 32)), [dq_lo] "s"((unsigned)dqp),
+                 [dq_hi] "s"((unsigned)(dqp >> 32)), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e),
+                 [scale] "s"(g.scale), [nloop] "s"((ntiles - 2) >> 1), [seq] "s"(g.S)
+               : ATTN_BWD_DQ64_CLOBBERS);
+#undef LOHI
+}
+
 }  // namespace
 
 extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* V, const uint16_t* Qt, const uint16_t* Kt,
@@ -533,7 +569,18 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   const int nb = cdiv(S, 256) * H * B;
   attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
 #ifndef MGX_DIAG_DKV_STAMPS
-  attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
+  const char* w64e = getenv("MGX_ATTN_W64");        // read per call: tests switch kernels inside one process
+  const int w64 = w64e ? atoi(w64e) : 1;
+  if (w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31)) {
+    static bool attr64 = false;
+    if (!attr64) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      attr64 = true;
+    }
+    attn_bwd_dq64_kernel<<<(S / 256) * H * B, 256, 98304, st>>>(g);
+  } else {
+    attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
+  }
 #endif
   MGX_CHECK_LAUNCH();
   return MGX_OK;

@@ -349,6 +349,17 @@ class Machine:
         w.scc = 1 if b_ > a_ else 0
         self._sdst(w, o[0], a_ - b_)
 
+    def i_s_subb_u32(self, w, ins, o):
+        a_, b_ = self.ssrc(w, o[1]), self.ssrc(w, o[2]) + w.scc
+        w.scc = 1 if b_ > a_ else 0
+        self._sdst(w, o[0], a_ - b_)
+
+    def i_s_cselect_b32(self, w, ins, o):
+        self._sdst(w, o[0], self.ssrc(w, o[1]) if w.scc else self.ssrc(w, o[2]))
+
+    def i_s_cmp_ge_u32(self, w, ins, o):
+        w.scc = int(self.ssrc(w, o[0]) >= self.ssrc(w, o[1]))
+
     def i_s_lshl_b32(self, w, ins, o):
         self._sdst(w, o[0], self.ssrc(w, o[1]) << (self.ssrc(w, o[2]) & 31))
 
@@ -586,7 +597,7 @@ class Machine:
         data = np.empty(1024, np.uint8)
         for l in range(64):
             data[16 * l:16 * l + 16] = self.gload(base + int(off[l]), 16)
-        lds_addr = w.m0 & 0xFFFF
+        lds_addr = w.m0 & 0x3FFFF          # gfx950: 160 KiB of LDS, the GEMM's DMA writes at m0 = 0x18000 + ...
         if lds_addr + 1024 > self.lds.size:
             raise RuntimeError(f"LDS-DMA beyond LDS: m0 = {lds_addr}")
         w.vm.append(("lds", lds_addr, data))
@@ -599,6 +610,17 @@ class Machine:
         data = np.empty((4, 64), U32)
         for l in range(64):
             data[:, l] = self.gload(base + int(off[l]), 16).view(U32)
+        f, i, n = reg_range(o[0])
+        w.vm.append(("reg", f, i, data))
+        if self.mode == "early":
+            self._retire_vm(w, 0)
+
+    def i_global_load_dword(self, w, ins, o):
+        base = self.ssrc64(w, o[2])
+        off = self.src(w, o[1]).astype(np.int64) + ins.mods.get("offset", 0)
+        data = np.empty((1, 64), U32)
+        for l in range(64):
+            data[0, l] = self.gload(base + int(off[l]), 4).view(U32)[0]
         f, i, n = reg_range(o[0])
         w.vm.append(("reg", f, i, data))
         if self.mode == "early":

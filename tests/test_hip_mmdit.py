@@ -219,6 +219,39 @@ def test_attention_fwd64_rescale_path():
     assert torch.allclose(lse, torch.logsumexp(s, -1), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,S,ldo_mult", [(1, 2, 256, 1), (2, 3, 768, 5), (1, 6, 1536, 1)])
+def test_attention_bwd64_vs_autograd_and_vs_the_8_wave_kernels(B, H, S, ldo_mult, monkeypatch):
+    """The 64-wide backward kernels (S % 256 == 0: generated instruction streams, csrc/gen/attn_bwd_*64.py) against torch
+    autograd of softmax(Q K^T / sqrt(d)) V in fp32, and against the 8-wave kernels on the same operands (MGX_ATTN_W64=0)."""
+    from mixgrpo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + 7 * H)
+    q, k, v = (torch.randn(B, H, S, 128, device="cuda", generator=g).bfloat16() for _ in range(3))
+    ldo = H * 128 * ldo_mult
+    do = torch.randn(B, S, ldo, device="cuda", generator=g).bfloat16()
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) / math.sqrt(128)
+    o_ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, S, H * 128)
+    o_ref.backward(do[:, :, :H * 128].float())
+    tr = lambda t: t.transpose(-1, -2).contiguous()
+    vt, qt, kt = tr(v), tr(q), tr(k)
+    outs = []
+    for w64 in ("1", "0"):
+        monkeypatch.setenv("MGX_ATTN_W64", w64)
+        O = torch.zeros(B, S, ldo, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, S, device="cuda")
+        ops.attn_fwd(q, k, vt, O, lse, B, H, S, S, ldo, S * ldo, 1 / math.sqrt(128))
+        dQ, dK, dV = (torch.full_like(q, float("nan")) for _ in range(3))
+        delta = torch.empty(B, H, S, device="cuda")
+        dOt = torch.zeros(B, H, 128, S, device="cuda", dtype=torch.bfloat16)
+        ops.attn_bwd(q, k, v, qt, kt, O, do, lse, delta, dOt, dQ, dK, dV, B, H, S, S, ldo, S * ldo, 1 / math.sqrt(128))
+        assert rel_err(dV, vf.grad) < 1e-2
+        assert rel_err(dK, kf.grad) < 1.5e-2
+        assert rel_err(dQ, qf.grad) < 1.5e-2
+        outs.append((dQ, dK, dV))
+    for a_, b_ in zip(*outs):
+        assert rel_err(a_, b_.float()) < 8e-3
+
+
 def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
     """The training forward keeps the attention output / LSE and the pre-gate outputs of to_out, ff.net.2 and proj_out so
     that the recompute pass skips attention and those GEMMs (flux_backward._Train.keep).  The kept values are the very
