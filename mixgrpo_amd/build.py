@@ -46,10 +46,12 @@ def _generate():
     """Rewrite the generated instruction streams (csrc/gen/*.py -> csrc/*_body.inc); files are only touched on change."""
     sys.path.insert(0, os.path.join(CSRC, "gen"))
     try:
+        import attn_bwd_dkv64
         import attn_bwd_dq64
         import attn_fwd64
         attn_fwd64.write()
         attn_bwd_dq64.write()
+        attn_bwd_dkv64.write()
     finally:
         sys.path.pop(0)
 

@@ -113,7 +113,7 @@ struct BwdArgs {
   bf16_raw* dV;
   int B, H, S, Sp;
   long ldo, o_bstride;
-  float scale, scale_log2e;
+  float scale, scale_log2e, neg_inv_scale;
 };
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -545,6 +545,44 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dq64_kernel(BwdArgs g) {
 #undef LOHI
 }
 
+// ------------------------------------------------------------------------------------------------ dK, dV, 64-key waves
+// attn_bwd_dkv64_kernel: 4 waves x 64 keys (two 32-key chains sharing every Q / dO / Q^T / dO^T fragment), one wave per SIMD,
+// dV^T and dK^T of both chains in all 256 accumulator registers; generated stream: csrc/gen/attn_bwd_dkv64.py.
+#include "attn_bwd_dkv64_body.inc"
+
+__global__ void __launch_bounds__(256, 1) attn_bwd_dkv64_kernel(BwdArgs g) {
+  const int nkb = g.S >> 8;
+  int bid = blockIdx.x;
+  xcd_remap(bid, nkb * g.H * g.B);
+  const int kt = bid % nkb, bh = bid / nkb;
+  const int b = bh / g.H, hh = bh - b * g.H;
+  const long bhS = (long)bh * g.S;
+  const unsigned long long qp = (unsigned long long)(g.Q + bhS * HD);
+  const unsigned long long dop = (unsigned long long)(g.dO + (long)b * g.o_bstride + hh * HD);
+  const unsigned long long qtp = (unsigned long long)(g.Qt + (long)bh * HD * g.Sp);
+  const unsigned long long dotp = (unsigned long long)(g.dOt + (long)bh * HD * g.Sp);
+  const unsigned long long kp = (unsigned long long)(g.K + (bhS + kt * 256) * HD);
+  const unsigned long long vp = (unsigned long long)(g.V + (bhS + kt * 256) * HD);
+  const unsigned long long lsep = (unsigned long long)(g.lse + bhS);
+  const unsigned long long dlp = (unsigned long long)(g.delta + bhS);
+  const unsigned long long dkp = (unsigned long long)(g.dK + (bhS + kt * 256) * HD);
+  const unsigned long long dvp = (unsigned long long)(g.dV + (bhS + kt * 256) * HD);
+  const int nq = g.S >> 5;
+#define LO(x) "s"((unsigned)(x))
+#define HI(x) "s"((unsigned)((x) >> 32))
+  asm volatile(ATTN_BWD_DKV64_BODY
+               :
+               : [tid] "v"(threadIdx.x), [q_lo] LO(qp), [q_hi] HI(qp), [do_lo] LO(dop), [do_hi] HI(dop), [qt_lo] LO(qtp),
+                 [qt_hi] HI(qtp), [dot_lo] LO(dotp), [dot_hi] HI(dotp), [k_lo] LO(kp), [k_hi] HI(kp), [v_lo] LO(vp), [v_hi] HI(vp),
+                 [lse_lo] LO(lsep), [lse_hi] HI(lsep), [dl_lo] LO(dlp), [dl_hi] HI(dlp), [dk_lo] LO(dkp), [dk_hi] HI(dkp),
+                 [dv_lo] LO(dvp), [dv_hi] HI(dvp), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e),
+                 [scale] "s"(g.scale), [nis] "s"(g.neg_inv_scale), [nloop] "s"((nq - 2) >> 1), [qmax] "s"((nq - 1) * 8192),
+                 [ldo32] "s"((int)(g.ldo * 64)), [cmax] "s"((nq - 1) * 128)
+               : ATTN_BWD_DKV64_CLOBBERS);
+#undef LO
+#undef HI
+}
+
 }  // namespace
 
 extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* V, const uint16_t* Qt, const uint16_t* Kt,
@@ -559,7 +597,7 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   BwdArgs g;
   g.Q = Q; g.K = K; g.V = V; g.Qt = Qt; g.Kt = Kt; g.dO = dO; g.dOt = dOt; g.lse = lse; g.delta = delta;
   g.dQ = dQ; g.dK = dK; g.dV = dV; g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
-  g.scale = scale; g.scale_log2e = scale * 1.4426950408889634f;
+  g.scale = scale; g.scale_log2e = scale * 1.4426950408889634f; g.neg_inv_scale = -1.0f / scale;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_STAGE + 65536);
@@ -567,18 +605,24 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
     attr = true;
   }
   const int nb = cdiv(S, 256) * H * B;
-  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
-#ifndef MGX_DIAG_DKV_STAMPS
   const char* w64e = getenv("MGX_ATTN_W64");        // read per call: tests switch kernels inside one process
   const int w64 = w64e ? atoi(w64e) : 1;
-  if (w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31)) {
+  // the generated 64-wide kernels: S % 256 == 0, 32-bit offsets inside a 256-row block of dO, 24-bit row * ldo products
+  const bool wide = w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31) && ldo * 2 < (1L << 24) && Sp * 2 < (1L << 24);
+#ifdef MGX_DIAG_DKV_STAMPS
+  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);
+#else
+  if (wide) {
     static bool attr64 = false;
     if (!attr64) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 149504);
       attr64 = true;
     }
-    attn_bwd_dq64_kernel<<<(S / 256) * H * B, 256, 98304, st>>>(g);
+    attn_bwd_dkv64_kernel<<<nb, 256, 149504, st>>>(g);
+    attn_bwd_dq64_kernel<<<nb, 256, 98304, st>>>(g);
   } else {
+    attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
     attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
   }
 #endif

@@ -360,6 +360,11 @@ class Machine:
     def i_s_cmp_ge_u32(self, w, ins, o):
         w.scc = int(self.ssrc(w, o[0]) >= self.ssrc(w, o[1]))
 
+    def i_s_and_b32(self, w, ins, o):
+        r = self.ssrc(w, o[1]) & self.ssrc(w, o[2])
+        w.scc = int(r != 0)
+        self._sdst(w, o[0], r)
+
     def i_s_lshl_b32(self, w, ins, o):
         self._sdst(w, o[0], self.ssrc(w, o[1]) << (self.ssrc(w, o[2]) & 31))
 
@@ -459,6 +464,27 @@ class Machine:
 
     def i_v_add_u32(self, w, ins, o):
         self.wr(w, o[0], (self.src(w, o[1]).astype(np.uint64) + self.src(w, o[2])).astype(U32))
+
+    def i_v_add_co_u32(self, w, ins, o):
+        assert o[1] == "vcc"
+        r = self.src(w, o[2]).astype(np.uint64) + self.src(w, o[3])
+        self._cmp(w, r >> np.uint64(32) != 0)
+        self.wr(w, o[0], r.astype(U32))
+
+    def i_v_addc_co_u32(self, w, ins, o):
+        assert o[1] == "vcc" and o[4] == "vcc"
+        cin = np.array([(w.vcc >> l) & 1 for l in range(64)], dtype=np.uint64)
+        r = self.src(w, o[2]).astype(np.uint64) + self.src(w, o[3]) + cin
+        self._cmp(w, r >> np.uint64(32) != 0)
+        self.wr(w, o[0], r.astype(U32))
+
+    def i_v_cndmask_b32(self, w, ins, o):
+        sel = np.array([(w.vcc >> l) & 1 for l in range(64)], dtype=bool)
+        self.wr(w, o[0], np.where(sel, self.src(w, o[2]), self.src(w, o[1])))
+
+    def i_v_cmp_lt_u32(self, w, ins, o):
+        assert o[0] == "vcc"
+        self._cmp(w, self.src(w, o[1]) < self.src(w, o[2]))
 
     def i_v_sub_u32(self, w, ins, o):
         self.wr(w, o[0], (self.src(w, o[1]).astype(np.int64) - self.src(w, o[2]).astype(np.int64)).astype(U32))
@@ -597,9 +623,24 @@ class Machine:
         data = np.empty(1024, np.uint8)
         for l in range(64):
             data[16 * l:16 * l + 16] = self.gload(base + int(off[l]), 16)
-        lds_addr = w.m0 & 0x3FFFF          # gfx950: 160 KiB of LDS, the GEMM's DMA writes at m0 = 0x18000 + ...
+        # LDS address = M0 + instruction offset + lane * 16: the instruction offset applies to BOTH addresses (found on the
+        # GPU: the dK/dV kernel's V fragments landed 32 ks bytes off); gfx950: M0 holds all 18 bits (160 KiB of LDS)
+        lds_addr = (w.m0 & 0x3FFFF) + ins.mods.get("offset", 0)
         if lds_addr + 1024 > self.lds.size:
             raise RuntimeError(f"LDS-DMA beyond LDS: m0 = {lds_addr}")
+        w.vm.append(("lds", lds_addr, data))
+        if self.mode == "early":
+            self._retire_vm(w, 0)
+
+    def i_global_load_lds_dword(self, w, ins, o):
+        r = reg_range(o[0])
+        assert r and r[2] == 2 and o[1] == "off", ins.text
+        lo, hi = self.src(w, f"v{r[1]}").astype(np.uint64), self.src(w, f"v{r[1] + 1}").astype(np.uint64)
+        addr = lo | (hi << np.uint64(32))
+        data = np.empty(256, np.uint8)
+        for l in range(64):
+            data[4 * l:4 * l + 4] = self.gload(int(addr[l]) + ins.mods.get("offset", 0), 4)
+        lds_addr = (w.m0 & 0x3FFFF) + ins.mods.get("offset", 0)
         w.vm.append(("lds", lds_addr, data))
         if self.mode == "early":
             self._retire_vm(w, 0)

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", "mixgrpo_amd", "csrc", "gen"))
 import asm_emu  # noqa: E402
+import attn_bwd_dkv64 as GK  # noqa: E402
 import attn_bwd_dq64 as GQ  # noqa: E402
 
 
@@ -60,9 +61,55 @@ def _emulate_dq(S, mode, order, seed=0, qt=0):
     return np.linalg.norm(got - want) / np.linalg.norm(want), m
 
 
+def _emulate_dkv(S, mode, order, seed=0, kt=0):
+    pr, ref = _problem(S, seed)
+    dK, dV = np.zeros((S, 128), np.uint16), np.zeros((S, 128), np.uint16)
+    DOT = np.ascontiguousarray(pr["DO"][:, pr["col0"]:pr["col0"] + 128].T)
+    NQ, ldo = S // 32, pr["ldo"]
+    inputs = dict(tid=np.arange(256).reshape(4, 64), q=("ptr", "Q", 0), do=("ptr", "DO", 2 * pr["col0"]), qt=("ptr", "QT", 0),
+                  dot=("ptr", "DOT", 0), k=("ptr", "K", kt * 65536), v=("ptr", "V", kt * 65536), lse=("ptr", "LSE", 0),
+                  dl=("ptr", "DL", 0), dk=("ptr", "DK", kt * 65536), dv=("ptr", "DV", kt * 65536), sp2=S * 2, ldo2=ldo * 2,
+                  cs=float(np.float32(pr["scale"] * 1.4426950408889634)), scale=float(np.float32(pr["scale"])),
+                  nis=float(np.float32(-1.0 / pr["scale"])), nloop=(NQ - 2) // 2, qmax=(NQ - 1) * 8192, ldo32=64 * ldo,
+                  cmax=(NQ - 1) * 128)
+    bufs = {k_: pr[k_] for k_ in ("Q", "K", "V", "QT", "DO", "LSE", "DL")}
+    bufs.update(DOT=DOT, DK=dK, DV=dV)
+    m = asm_emu.Machine(GK.generate(), inputs, bufs, lds_bytes=GK.LDS_BYTES, mode=mode, order=order).run()
+    sl = slice(kt * 256, kt * 256 + 256)
+    rels = []
+    for nm, arr in (("dK", dK), ("dV", dV)):
+        got, want = _f32(arr[sl]).astype(np.float64), ref[nm][sl]
+        rels.append(np.linalg.norm(got - want) / np.linalg.norm(want))
+        assert not np.delete(arr, np.s_[sl], axis=0).any(), "stores outside this workgroup's key block"
+    return rels, m
+
+
 def test_generated_files_are_current():
-    with open(GQ.OUT_BODY) as f:
-        assert f.read() == GQ.render(), "run `python -m mixgrpo_amd.build`"
+    for G in (GQ, GK):
+        with open(G.OUT_BODY) as f:
+            assert f.read() == G.render(), "run `python -m mixgrpo_amd.build`"
+
+
+def test_dkv64_static_hazards_clean():
+    text = GK.generate()
+    assert asm_emu.check_hazards(text) == []
+    lines = text.split("\n")
+    lo = next(i for i, ln in enumerate(lines) if ln.startswith(".Lloop_"))
+    hi = next(i for i, ln in enumerate(lines) if ln.startswith(".Lloopdone_"))
+    assert asm_emu.check_hazards("\n".join(lines[lo + 1:hi] + lines[lo + 1:hi])) == []
+
+
+@pytest.mark.parametrize("mode,order", [("late", [0, 1, 2, 3]), ("early", [3, 2, 1, 0])])
+def test_dkv64_emulated_vs_reference(mode, order):
+    (rk, rv), m = _emulate_dkv(256, mode, order)            # 8 query blocks: first, three loop trips, last, tail
+    assert rk < 4e-3 and rv < 4e-3
+    assert m.mfma_count == 4 * 8 * 64
+
+
+@pytest.mark.parametrize("mode,order", [("late", [2, 0, 3, 1]), ("early", [1, 3, 0, 2])])
+def test_dkv64_emulated_second_key_block(mode, order):
+    (rk, rv), _ = _emulate_dkv(512, mode, order, seed=1, kt=1)
+    assert rk < 4e-3 and rv < 4e-3
 
 
 def test_dq64_static_hazards_clean():
