@@ -8,12 +8,15 @@ FlowMatchEulerDiscreteScheduler with `use_dynamic_shifting`), the update an Eule
 dtype.  Text encoders, the VAE and PIL output are outside the hot path: the sampler takes cached prompt embeddings and
 returns packed latents (`unpack_latents` + VAE decode is the caller's, as in train_grpo_flux.py:279-289).
 
-`calculate_shift` / the scheduler live in diffusers==0.32.2 (absent offline; the reference only imports them, :7):
-the arithmetic below restates the published algorithm -- PARITY UNPINNED against diffusers, checked against
-oracle/sampler.py (the same restatement on the CPU oracle MMDiT).
+`calculate_shift` and the sigma grid handed to the scheduler are held bit for bit to the reference's vendored helpers
+(fastvideo/models/flux_hf/pipeline_flux.py:73-84,87-145; tests/test_sampler_host.py, tests/golden/sampler_schedule.json).
+The scheduler itself (dynamic shift, Euler step) lives in diffusers==0.32.2 (absent offline): that arithmetic restates the
+published algorithm -- PARITY UNPINNED against diffusers, checked against oracle/sampler.py (the same restatement on the
+CPU oracle MMDiT).
 """
 import math
 
+import numpy as np
 import torch
 
 from .latents import prepare_latent_image_ids
@@ -30,7 +33,8 @@ def flow_match_sigmas(num_inference_steps, mu, sigmas=None):
     """FlowMatchEulerDiscreteScheduler.set_timesteps(sigmas=linspace(1, 1/T, T), mu=mu) with dynamic shifting:
     sigma' = e^mu / (e^mu + (1/sigma - 1)); returns (sigmas' + [0], timesteps = sigmas' * 1000) as fp32 tensors."""
     if sigmas is None:
-        sigmas = torch.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps, dtype=torch.float64)
+        # the reference's grid is numpy's (sample_flux.py:249); torch.linspace differs from it in the last bits
+        sigmas = torch.from_numpy(np.linspace(1.0, 1 / num_inference_steps, num_inference_steps))
     else:
         sigmas = torch.as_tensor(sigmas, dtype=torch.float64)
     shifted = math.exp(mu) / (math.exp(mu) + (1.0 / sigmas - 1.0))

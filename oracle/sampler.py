@@ -1,11 +1,16 @@
 """CPU restatement of the reference's mixed-model inference loop (fastvideo/sample/sample_flux.py:249-264, 308-365)
 on the oracle MMDiT -- TEST INFRASTRUCTURE ONLY (imported by tests/ alone).
 
-PARITY UNPINNED: `calculate_shift`, `retrieve_timesteps` and FlowMatchEulerDiscreteScheduler live in
-diffusers==0.32.2 (absent offline; no fixture in the reference covers them); this follows their published
-algorithm: mu linear in the image token count, sigma' = e^mu / (e^mu + 1/sigma - 1), Euler update in fp32.
+PINNED to the reference (tests/test_sampler_host.py, fixtures tests/golden/sampler_schedule.json produced by
+gen_fixtures.py from the reference's OWN vendored helpers, fastvideo/models/flux_hf/pipeline_flux.py:73-84,87-145):
+`calculate_shift` bit for bit, and the unshifted sigma grid + mu that `retrieve_timesteps` hands to the scheduler.
+PARITY UNPINNED: what the scheduler does with them -- FlowMatchEulerDiscreteScheduler.set_timesteps (the dynamic shift
+sigma' = e^mu / (e^mu + 1/sigma - 1)) and .step (Euler update in fp32) live in diffusers==0.32.2, absent offline, and the
+reference holds no fixture of either; this follows their published algorithm.
 """
 import math
+
+import numpy as np
 
 import torch
 
@@ -17,8 +22,13 @@ def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shif
     return image_seq_len * m + (base_shift - m * base_seq_len)
 
 
+def sigma_grid(num_inference_steps):
+    """np.linspace(1.0, 1 / T, T) of sample_flux.py:249, in float64 (numpy's own: torch.linspace differs in the last bits)."""
+    return torch.from_numpy(np.linspace(1.0, 1 / num_inference_steps, num_inference_steps))
+
+
 def sigmas_for(num_inference_steps, n_img):
-    s = torch.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps, dtype=torch.float64)
+    s = sigma_grid(num_inference_steps)
     mu = calculate_shift(n_img)
     s = (math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0))).float()
     return torch.cat([s, torch.zeros(1)])

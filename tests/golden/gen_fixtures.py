@@ -305,7 +305,8 @@ def _make_stub(name):
         return object.__new__(cls)
     return _StubMeta(name.split(".")[-1], (), {"__new__": _call, "__init__": lambda self, *a, **k: None,
                                                "__getattr__": lambda self, n: _make_stub(n),
-                                               "__call__": lambda self, *a, **k: self})
+                                               "__call__": lambda self, *a, **k: (a[0] if len(a) == 1 and not k and callable(a[0])
+                                                                                 and not isinstance(a[0], type) else self)})
 
 
 class _StubModule(types.ModuleType):
@@ -516,8 +517,45 @@ def gen_mmdit_witness():
     return t, meta
 
 
+# --------------------------------------------------------------------------- inference sampler schedule
+def gen_sampler():
+    """The two schedule helpers the reference VENDORS as plain Python (fastvideo/models/flux_hf/pipeline_flux.py:73-84,
+    87-145; call site fastvideo/sample/sample_flux.py:248-264): `calculate_shift` values, and what `retrieve_timesteps`
+    hands to the scheduler (recorded by a fake scheduler: the unshifted sigma grid, mu, and what it returns).  The
+    scheduler's own shifting / stepping lives in diffusers (absent) and stays unpinned."""
+    # the real transformers classes the module imports, BEFORE the stub finder (it would serve a version-less torchvision)
+    from transformers import (CLIPImageProcessor, CLIPTextModel, CLIPTokenizer, CLIPVisionModelWithProjection,  # noqa: F401
+                              T5EncoderModel, T5TokenizerFast)
+    for k in [k for k in sys.modules if k.split(".")[0] == "diffusers"]:
+        del sys.modules[k]
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _StubFinder())
+    pf = load_ref("ref_pipeline_flux", "fastvideo/models/flux_hf/pipeline_flux.py")
+    out = {"calculate_shift": {}, "retrieve_timesteps": []}
+    for n in (256, 512, 1024, 1536, 2025, 2304, 3072, 4096):
+        out["calculate_shift"][str(n)] = {"default": pf.calculate_shift(n),
+                                          "flux_config": pf.calculate_shift(n, 256, 4096, 0.5, 1.15)}
+
+    class Recorder:
+        order = 1
+
+        def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+            self.seen = dict(num_inference_steps=num_inference_steps, device=device,
+                             sigmas=None if sigmas is None else [float(x) for x in sigmas], mu=mu)
+            self.timesteps = torch.arange(len(sigmas) if sigmas is not None else num_inference_steps)
+
+    for T, n_img in ((28, 4096), (50, 1024), (8, 256)):
+        sig = np.linspace(1.0, 1 / T, T)                    # sample_flux.py:249
+        mu = pf.calculate_shift(n_img, 256, 4096, 0.5, 1.15)
+        r = Recorder()
+        ts, nst = pf.retrieve_timesteps(r, T, "cpu", sigmas=sig, mu=mu)
+        out["retrieve_timesteps"].append({"T": T, "n_img": n_img, "mu": mu, "passed": r.seen, "returned_len": len(ts),
+                                          "returned_steps": int(nst)})
+    return out
+
+
 def main():
-    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer", "mmdit"]
+    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer", "mmdit", "sampler"]
     install_light_stub()
     su = load_ref("ref_sampling_utils", "fastvideo/utils/sampling_utils.py")
     if "solver" in which:
@@ -539,6 +577,9 @@ def main():
         save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(HERE, "mmdit_witness.safetensors"))
         json.dump(m, open(os.path.join(HERE, "mmdit_witness.json"), "w"), indent=1)
         print("mmdit witness:", len(t), "tensors")
+    if "sampler" in which:
+        json.dump(gen_sampler(), open(os.path.join(HERE, "sampler_schedule.json"), "w"), indent=1)
+        print("sampler schedule ok")
     if "trainer" in which:
         tg = load_trainer()
         t, m = gen_trainer(tg)

@@ -26,3 +26,27 @@ def test_sigma_schedule_matches_oracle_and_formula():
         mu = SF.calculate_shift(n)
         s_last = 1.0 / T
         assert abs(sig[T - 1].item() - math.exp(mu) / (math.exp(mu) + (1 / s_last - 1))) < 1e-6
+
+
+def test_schedule_helpers_pinned_to_the_reference():
+    """`calculate_shift` and the sigma grid / mu that reach the scheduler, against values produced by the reference's own
+    vendored helpers (fastvideo/models/flux_hf/pipeline_flux.py:73-84,87-145 through tests/golden/gen_fixtures.py sampler;
+    call site fastvideo/sample/sample_flux.py:248-264).  Bit for bit in float64."""
+    import json
+    import os
+    import numpy as np
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sampler_schedule.json")) as f:
+        fx = json.load(f)
+    for n, vals in fx["calculate_shift"].items():
+        for impl in (SF.calculate_shift, OS.calculate_shift):
+            assert impl(int(n)) == vals["default"] == vals["flux_config"], (n, impl(int(n)), vals)
+            assert impl(int(n), 256, 4096, 0.5, 1.15) == vals["flux_config"]
+    for case in fx["retrieve_timesteps"]:
+        T, n_img = case["T"], case["n_img"]
+        assert SF.calculate_shift(n_img) == case["mu"] == case["passed"]["mu"]
+        assert case["passed"]["num_inference_steps"] is None and case["returned_steps"] == T == case["returned_len"]
+        grid = np.asarray(case["passed"]["sigmas"])
+        assert np.array_equal(OS.sigma_grid(T).numpy(), grid)                   # the oracle's grid
+        sig, ts = SF.flow_match_sigmas(T, case["mu"], sigmas=grid)              # the product takes the same grid ...
+        sig2, _ = SF.flow_match_sigmas(T, case["mu"])                           # ... and builds the same one itself
+        assert torch.equal(sig, sig2) and sig.shape == (T + 1,) and sig[-1] == 0 and torch.equal(ts, sig[:-1] * 1000.0)
