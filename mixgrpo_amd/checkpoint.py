@@ -54,6 +54,48 @@ def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, 
     os.replace(tmp_j, os.path.join(save_dir, "trainer_state.json"))
 
 
+def save_rng_state(save_dir, rank=0):
+    """Every rank's generator states (python, numpy, torch CPU, torch device) next to the resume state, so that a resumed run
+    draws the rollout noise the uninterrupted run would have drawn.  Plain tensors + JSON: loaded without unpickling."""
+    import random
+
+    import numpy as np
+    from safetensors.torch import save_file
+    os.makedirs(save_dir, exist_ok=True)
+    tensors = {"torch_cpu": torch.get_rng_state()}
+    if torch.cuda.is_available():
+        tensors["torch_cuda"] = torch.cuda.get_rng_state()
+    np_state = np.random.get_state()
+    tensors["numpy_keys"] = torch.from_numpy(np_state[1].astype("int64"))
+    py = random.getstate()
+    meta = {"python": [py[0], list(py[1]), py[2]], "numpy": [np_state[0], int(np_state[2]), int(np_state[3]), float(np_state[4])]}
+    save_file(tensors, os.path.join(save_dir, f"rng_state_rank{rank}.safetensors"))
+    with open(os.path.join(save_dir, f"rng_state_rank{rank}.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def load_rng_state(save_dir, rank=0):
+    """Restores what `save_rng_state` wrote; returns False when the directory holds none for this rank."""
+    import random
+
+    import numpy as np
+    from safetensors.torch import load_file
+    path = os.path.join(save_dir, f"rng_state_rank{rank}.safetensors")
+    if not os.path.exists(path):
+        return False
+    tensors = load_file(path)
+    with open(os.path.join(save_dir, f"rng_state_rank{rank}.json")) as f:
+        meta = json.load(f)
+    torch.set_rng_state(tensors["torch_cpu"])
+    if "torch_cuda" in tensors and torch.cuda.is_available():
+        torch.cuda.set_rng_state(tensors["torch_cuda"])
+    n = meta["numpy"]
+    np.random.set_state((n[0], tensors["numpy_keys"].numpy().astype("uint32"), n[1], n[2], n[3]))
+    py = meta["python"]
+    random.setstate((py[0], tuple(py[1]), py[2]))
+    return True
+
+
 def _json_scalar(x):
     """numpy scalars (the exp_decay budget is a numpy float, window indices may be numpy ints) as python numbers."""
     if hasattr(x, "item"):

@@ -605,12 +605,27 @@ class FluxTransformer2DModel(torch.nn.Module):
             json.dump(cfg, f, indent=4)
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda"):
+    def from_pretrained(cls, path, device="cuda", subfolder=None, torch_dtype=None):
+        """`FluxTransformer2DModel.from_pretrained(model_path, subfolder="transformer", torch_dtype=torch.float32)` as the
+        reference calls it (train_grpo_flux.py:677-679): config.json + diffusers-named safetensors, single file or the
+        sharded layout of the published FLUX.1-dev checkpoint (`...safetensors.index.json`).  Master weights are always
+        fp32 (`torch_dtype` is accepted for the call signature)."""
         from safetensors.torch import load_file
+        if subfolder and os.path.isdir(os.path.join(path, subfolder)):
+            path = os.path.join(path, subfolder)
         with open(os.path.join(path, "config.json")) as f:
             raw = json.load(f)
         keys = {f.name for f in FluxConfig.__dataclass_fields__.values()}
         cfg = FluxConfig(**{k: (tuple(v) if k == "axes_dims_rope" else v) for k, v in raw.items() if k in keys})
         m = cls(cfg, device=device)
-        m.load_state_dict(load_file(os.path.join(path, "diffusion_pytorch_model.safetensors")))
+        index = os.path.join(path, "diffusion_pytorch_model.safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            sd = {}
+            for shard in shards:
+                sd.update(load_file(os.path.join(path, shard)))
+        else:
+            sd = load_file(os.path.join(path, "diffusion_pytorch_model.safetensors"))
+        m.load_state_dict(sd)
         return m

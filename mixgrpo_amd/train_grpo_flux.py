@@ -413,3 +413,248 @@ def _replay_backward(args, transformer, pairs, lat_steps, all_log_probs, adv, eh
     if trace is not None:
         trace.setdefault("new_log_probs", []).append((list(pairs), new_lp.clone()))
         trace.setdefault("g_logp", []).append(g_lp.clone())
+
+
+# ------------------------------------------------------------------------------------------------ entry point
+# `torchrun ... -m mixgrpo_amd.train_grpo_flux <the flags of scripts/finetune/finetune_flux_grpo_MixGRPO.sh:120-196>`:
+# the reference's command-line surface (fastvideo/train_grpo_flux.py:894-1423) and its main loop (:627-892).
+
+# (flag, type, default, choices): every flag the reference's parser defines; SURVEY.md Appendix D says which are read on the hot
+# path, which only in main(), and which this fork defines but never reads (accepted and ignored here as well)
+_VALUE_FLAGS = (
+    ("data_json_path", str, None, None), ("dataloader_num_workers", int, 10, None), ("train_batch_size", int, 16, None),
+    ("num_latent_t", int, 1, None), ("pretrained_model_name_or_path", str, None, None),
+    ("dit_model_name_or_path", str, None, None), ("vae_model_path", str, None, None), ("cache_dir", str, "./cache_dir", None),
+    ("ema_decay", float, 0.995, None), ("ema_start_step", int, 0, None), ("cfg", float, 0.0, None), ("seed", int, None, None),
+    ("output_dir", str, None, None), ("checkpointing_steps", int, 500, None), ("resume_from_checkpoint", str, None, None),
+    ("logging_dir", str, "logs", None), ("max_train_steps", int, None, None), ("gradient_accumulation_steps", int, 1, None),
+    ("learning_rate", float, 1e-4, None), ("lr_warmup_steps", int, 10, None), ("max_grad_norm", float, 2.0, None),
+    ("selective_checkpointing", float, 1.0, None), ("mixed_precision", str, None, ("no", "fp16", "bf16")),
+    ("sp_size", int, 1, None), ("train_sp_batch_size", int, 1, None), ("fsdp_sharding_startegy", str, "full", None),
+    ("lr_scheduler", str, "constant_with_warmup", None), ("lr_num_cycles", int, 1, None), ("lr_power", float, 1.0, None),
+    ("weight_decay", float, 0.01, None), ("master_weight_type", str, "fp32", None), ("h", int, None, None),
+    ("w", int, None, None), ("t", int, None, None), ("sampling_steps", int, None, None), ("eta", float, None, None),
+    ("sampler_seed", int, None, None), ("loss_coef", float, 1.0, None), ("num_generations", int, 16, None),
+    ("shift", float, 1.0, None), ("timestep_fraction", float, 1.0, None), ("clip_range", float, 1e-4, None),
+    ("adv_clip_max", float, 5.0, None), ("advantage_rerange_strategy", str, "null", ("random", "balance", "null")),
+    ("trimmed_ratio", float, 0.0, None), ("experiment_name", str, "test", None),
+    ("training_strategy", str, "all", ("part", "all")), ("frozen_init_timesteps", int, -1, None), ("kl_coeff", float, 0.01, None),
+    ("iters_per_group", int, 25, None), ("group_size", int, 4, None),
+    ("sample_strategy", str, "progressive", ("progressive", "random", "decay", "exp_decay")), ("prog_overlap_step", int, 1, None),
+    ("max_iters_per_group", int, 10, None), ("min_iters_per_group", int, 1, None),
+    ("reward_model", str, "hpsv2", ("hpsv2", "clip_score", "image_reward", "pick_score", "unified_reward", "hpsv2_clip_score",
+                                    "multi_reward")),
+    ("hps_path", str, "hps_ckpt/HPS_v2.1_compressed.pt", None), ("hps_clip_path", str, "hps_ckpt/open_clip_pytorch_model.bin", None),
+    ("clip_score_path", str, "hf-hub:apple/DFN5B-CLIP-ViT-H-14-384", None),
+    ("image_reward_path", str, "./image_reward_ckpt/ImageReward.pt", None),
+    ("image_reward_med_config", str, "./image_reward_ckpt/med_config.json", None), ("image_reward_http_proxy", str, None, None),
+    ("image_reward_https_proxy", str, None, None), ("pick_score_http_proxy", str, None, None),
+    ("pick_score_https_proxy", str, None, None), ("unified_reward_url", str, None, None),
+    ("unified_reward_default_question_type", str, None, None), ("unified_reward_num_workers", int, 1, None),
+    ("multi_reward_mix", str, "advantage_aggr", ("advantage_aggr", "reward_aggr")), ("hps_weight", float, 1.0, None),
+    ("clip_score_weight", float, 1.0, None), ("image_reward_weight", float, 1.0, None), ("pick_score_weight", float, 1.0, None),
+    ("unified_reward_weight", float, 1.0, None), ("dpm_algorithm_type", str, "null", ("null", "dpmsolver", "dpmsolver++")),
+    ("dpm_apply_strategy", str, "post", ("post", "all")), ("dpm_post_compress_ratio", float, 0.4, None),
+    ("dpm_solver_order", int, 2, (1, 2, 3)), ("dpm_solver_type", str, "heun", ("heun", "midpoint")), ("wandb_key", str, None, None),
+)
+_SWITCHES = ("precondition_outputs", "gradient_checkpointing", "allow_tf32", "use_cpu_offload", "use_group", "ignore_last",
+             "init_same_noise", "flow_grpo_sampling", "drop_last_sample", "prog_overlap", "roll_back")
+# engine options the reference has no flag for (all optional)
+_ENGINE_FLAGS = (("rollout_batch", int, 0), ("train_microbatch", int, 0), ("attention_dtype", str, "bf16"),
+                 ("mgx_max_epochs", int, None))
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="MixGRPO FLUX trainer on the MI355X-native engine (reference CLI surface)")
+    for name, typ, default, choices in _VALUE_FLAGS:
+        kw = dict(type=typ, default=default)
+        if choices is not None:
+            kw["choices"] = list(choices)
+        if name == "data_json_path":
+            kw["required"] = True
+        p.add_argument("--" + name, **kw)
+    for name in _SWITCHES:
+        p.add_argument("--" + name, action="store_true", default=False)
+    for name, typ, default in _ENGINE_FLAGS:
+        p.add_argument("--" + name, type=typ, default=default)
+    p.add_argument("--skip_dead_backward", action="store_true", default=False)
+    return p
+
+
+def set_seed(seed):
+    """accelerate.utils.set_seed (reference :656 `set_seed(args.seed + rank)`)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def _device_loader(dataloader, device):
+    """fastvideo/utils/communications_flux.py `sp_parallel_dataloader_wrapper` at sp_size 1: the dataloader, forever, with
+    the tensors moved to the device."""
+    while True:
+        for item in dataloader:
+            ehs, pooled, text_ids, caption = item
+            yield ehs.to(device), pooled.to(device), text_ids.to(device), caption
+
+
+def synthetic_reward_function(heads=("SyntheticReward",), seed=1234):
+    """Stand-in for decode + score when no reward function is handed to `main` (the reference's reward models need weights
+    that are not available offline; this fork's own `compute_reward` is broken): a deterministic
+    pseudo-reward per sample from the final latents, so that runs are reproducible and advantages are non-trivial."""
+    def fn(latents, captions):
+        flat = latents.detach().float().reshape(latents.shape[0], -1)
+        per = {}
+        for j, h in enumerate(heads):
+            w = torch.sin(torch.arange(flat.shape[1], device=flat.device, dtype=torch.float32) * (0.37 + 0.11 * j) + seed)
+            per[h] = torch.sigmoid((flat * w).mean(dim=1) * 40.0)
+        return sum(per.values()), per
+    return fn
+
+
+def reward_weights_from_args(args):
+    """Upstream keys `reward_weights` by reward CLASS name for the models `--reward_model` activates (eval_reward.py:185,224)."""
+    table = {"hpsv2": ("HPSClipRewardModel",), "clip_score": ("CLIPScoreRewardModel",), "image_reward": ("ImageRewardModel",),
+             "pick_score": ("PickScoreRewardModel",), "unified_reward": ("UnifiedRewardModel",),
+             "hpsv2_clip_score": ("HPSClipRewardModel", "CLIPScoreRewardModel"),
+             "multi_reward": ("HPSClipRewardModel", "ImageRewardModel", "PickScoreRewardModel")}
+    flag = {"HPSClipRewardModel": "hps_weight", "CLIPScoreRewardModel": "clip_score_weight", "ImageRewardModel": "image_reward_weight",
+            "PickScoreRewardModel": "pick_score_weight", "UnifiedRewardModel": "unified_reward_weight"}
+    return {name: float(getattr(args, flag[name])) for name in table[args.reward_model]}
+
+
+def main(args, reward_function=None, reward_weights=None):
+    """The reference's main() (:627-892) on this engine: replica data parallelism instead of FSDP (the flags that configure
+    FSDP / activation checkpointing / sequence parallelism are accepted and have no effect), a JSON log line per step instead of
+    wandb, and a `--resume_from_checkpoint` that actually resumes (weights, AdamW moments, LR position, SDE-window state, global
+    step and every rank's generator states)."""
+    import json
+    import os
+    import time
+    from collections import deque
+
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+
+    from .checkpoint import load_resume_state, load_rng_state, save_checkpoint, save_resume_state, save_rng_state
+    from .flux import FluxTransformer2DModel
+    from .grpo_states import GRPOTrainingStates
+    from .latent_flux_rl_datasets import LatentDataset, latent_collate_function
+    from .optim import ConstantWithWarmup, FusedAdamW
+
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    rk = int(os.environ.get("RANK", 0))
+    ws = int(os.environ.get("WORLD_SIZE", 1))
+    if ws > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if args.sp_size != 1:
+        raise ValueError("sp_size must be 1 for FLUX (the reference never uses sequence parallelism on this path)")
+    if args.lr_scheduler not in ("constant", "constant_with_warmup"):
+        raise ValueError(f"lr_scheduler {args.lr_scheduler!r}: only constant / constant_with_warmup (the shipped scripts' choice)")
+    if args.seed is not None:
+        set_seed(args.seed + rk)
+    run_dir = None
+    if args.output_dir is not None:
+        run_dir = f"{args.output_dir}/{args.training_strategy}_{args.experiment_name}"
+        if rk <= 0:
+            os.makedirs(run_dir, exist_ok=True)
+            with open(os.path.join(run_dir, "args.json"), "w") as f:
+                json.dump({k: v for k, v in vars(args).items()}, f, indent=4, default=str)
+
+    model_path = args.resume_from_checkpoint or args.pretrained_model_name_or_path
+    main_print(f"--> loading model from {model_path}")
+    transformer = FluxTransformer2DModel.from_pretrained(model_path, device=device, subfolder="transformer", torch_dtype=F32)
+    transformer.attention_dtype = args.attention_dtype
+    transformer.train()
+    optimizer = FusedAdamW(transformer, lr=args.learning_rate, betas=(0.9, 0.999), weight_decay=args.weight_decay, eps=1e-8)
+    lr_scheduler = ConstantWithWarmup(optimizer, args.lr_warmup_steps if args.lr_scheduler == "constant_with_warmup" else 0)
+
+    train_dataset = LatentDataset(args.data_json_path, args.num_latent_t, args.cfg)
+    sampler = DistributedSampler(train_dataset, rank=rk, num_replicas=ws, shuffle=True, seed=args.sampler_seed or 0)
+    train_dataloader = DataLoader(train_dataset, sampler=sampler, collate_fn=latent_collate_function, pin_memory=True,
+                                  batch_size=args.train_batch_size, num_workers=args.dataloader_num_workers, drop_last=True)
+    loader = _device_loader(train_dataloader, device)
+
+    if reward_function is None:
+        heads = ("SyntheticReward",)
+        reward_function = synthetic_reward_function(heads)
+        reward_weights = {h: 1.0 for h in heads}
+        main_print("--> no reward function given: synthetic rewards (decode + reward models are outside this engine)")
+    elif reward_weights is None:
+        reward_weights = reward_weights_from_args(args)
+
+    grpo_states = None
+    if args.training_strategy == "part":
+        grpo_states = GRPOTrainingStates(
+            iters_per_group=args.iters_per_group, group_size=args.group_size, max_timesteps=args.sampling_steps - 2,
+            cur_timestep=0, cur_iter_in_group=0, sample_strategy=args.sample_strategy, prog_overlap=args.prog_overlap,
+            prog_overlap_step=args.prog_overlap_step, max_iters_per_group=args.max_iters_per_group,
+            min_iters_per_group=args.min_iters_per_group, roll_back=args.roll_back)
+
+    init_steps = 0
+    if args.resume_from_checkpoint:
+        init_steps = load_resume_state(args.resume_from_checkpoint, optimizer, lr_scheduler, grpo_states)
+        load_rng_state(args.resume_from_checkpoint, rk)
+        main_print(f"--> resumed from {args.resume_from_checkpoint} at step {init_steps}")
+    main_print("***** Running training *****")
+    main_print(f"  Num examples = {len(train_dataset)}  world size = {ws}  resume step = {init_steps}")
+    main_print(f"  Gradient Accumulation steps = {args.gradient_accumulation_steps}  steps per epoch = {args.max_train_steps}")
+
+    step_times = deque(maxlen=100)
+    resumed, first_step = bool(args.resume_from_checkpoint), init_steps + 1      # (the resumed-from checkpoint is not rewritten)
+    global_step = init_steps - 1
+    log_path = os.path.join(run_dir, "train_log.jsonl") if run_dir and rk <= 0 else None
+    epochs = 1000000 if args.mgx_max_epochs is None else args.mgx_max_epochs
+    for epoch in range(epochs):
+        sampler.set_epoch(epoch)
+        for step in range(init_steps + 1, args.max_train_steps + 1):
+            global_step += 1
+            start_time = time.time()
+            if step % args.checkpointing_steps == 0 and run_dir is not None and not (resumed and step == first_step):
+                d = save_checkpoint(transformer, rk, run_dir, step, epoch)
+                # (what the NEXT step needs to continue: it is `step` itself that has not run yet)
+                save_resume_state(d, optimizer, lr_scheduler, grpo_states, global_step=step - 1, rank=rk)
+                if ws > 1:
+                    dist.barrier()                      # the directory exists before the other ranks write into it
+                save_rng_state(d, rk)
+                if ws > 1:
+                    dist.barrier()
+            if args.training_strategy == "part":
+                timesteps_train = grpo_states.get_current_timesteps()
+                grpo_states.update_iteration()
+            else:
+                timesteps_train = list(range(args.sampling_steps))
+            loss, grad_norm, policy_loss, kl_loss, clip_frac, reward = train_one_step(
+                args, device, transformer, None, reward_function, optimizer, lr_scheduler, loader, None, args.max_grad_norm,
+                timesteps_train, global_step, reward_weights)
+            step_time = time.time() - start_time
+            step_times.append(step_time)
+            if rk <= 0:
+                log = {"step": step, "global_step": global_step, "epoch": epoch, "train_loss": loss, "policy_loss": policy_loss,
+                       "kl_loss": kl_loss, "clip_frac": clip_frac, "grad_norm": grad_norm, "timesteps_train": list(timesteps_train),
+                       "cur_timesteps": grpo_states.cur_timestep if grpo_states else 0,
+                       "cur_iter_in_group": grpo_states.cur_iter_in_group if grpo_states else 0,
+                       "learning_rate": lr_scheduler.get_last_lr()[0], "step_time": step_time,
+                       "avg_step_time": sum(step_times) / len(step_times)}
+                if args.multi_reward_mix == "advantage_aggr" and isinstance(reward, dict):
+                    for name, val in reward.items():
+                        log[f"reward_{name}"] = val
+                else:
+                    log["reward"] = reward
+                line = json.dumps(log, default=lambda x: x.item() if hasattr(x, "item") else str(x))
+                print(line, flush=True)
+                if log_path:
+                    with open(log_path, "a") as f:
+                        f.write(line + "\n")
+        init_steps = 0
+    if ws > 1 and dist.is_initialized():
+        dist.barrier()
+    return transformer
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -35,11 +35,24 @@ class _Sched:
                                     dpm_post_compress_ratio=0.4), [0, 1]),
 ])
 def test_train_step_with_mmdit_vs_oracle(tag, over, window):
+    _train_step_vs_oracle(KW, over, window)
+
+
+def test_train_step_at_depth_vs_oracle():
+    """The same check with 4 double + 8 single blocks at FULL width (d = 3072, 24 heads, joint_attention_dim 4096, pooled 768;
+    2.5 B parameters): bf16 error compounds through 12 residual blocks, FLUX.1-dev runs 57.  Replayed log-probs after the
+    first optimizer update must stay inside the north star's 1e-3; the measured numbers are written to
+    gpurun_out/r03_depth_parity.json (DESIGN.md section 2 quotes them)."""
+    kw = dict(num_layers=4, num_single_layers=8)                     # every other field: the FLUX.1-dev default
+    _train_step_vs_oracle(kw, dict(), [1, 2], hw=64, std=0.02, second_bar=1e-3, loss_rel=0.15, record="e2e_4+8")
+
+
+def _train_step_vs_oracle(KW, over, window, hw=128, std=0.05, second_bar=5e-4, loss_rel=0.05, record=None):
     from mixgrpo_amd import train_grpo_flux as TG
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
     from mixgrpo_amd.optim import FusedAdamW
     dev = torch.device("cuda", 0)
-    a = Namespace(w=128, h=128, t=1, sampling_steps=6, shift=3.0, init_same_noise=True, training_strategy="part",
+    a = Namespace(w=hw, h=hw, t=1, sampling_steps=6, shift=3.0, init_same_noise=True, training_strategy="part",
                   output_dir="/tmp/x", experiment_name="t", reward_model="toy", multi_reward_mix="advantage_aggr",
                   use_group=True, num_generations=4, trimmed_ratio=0.0, advantage_rerange_strategy="null", clip_range=1e-4,
                   adv_clip_max=5.0, kl_coeff=0.0, gradient_accumulation_steps=2, frozen_init_timesteps=-1,
@@ -54,15 +67,15 @@ def test_train_step_with_mmdit_vs_oracle(tag, over, window):
     g = torch.Generator().manual_seed(11)
     inj = {"x_T": torch.randn(1, 16, lh, lw, generator=g).bfloat16(),
            "steps": [torch.randn(G, N, 64, generator=g).bfloat16() for _ in range(T)]}
-    ehs = (0.5 * torch.randn(1, 8, 64, generator=g)).bfloat16()
-    pooled = torch.randn(1, 32, generator=g).bfloat16()
+    ocfg = OM.FluxConfig(**KW)
+    ehs = (0.5 * torch.randn(1, 8, ocfg.joint_attention_dim, generator=g)).bfloat16()
+    pooled = torch.randn(1, ocfg.pooled_projection_dim, generator=g).bfloat16()
     text_ids = torch.zeros(1, 3)
     rewards = [0.1, 0.9, 0.3, 0.6]
     weights = {"A": 1.0}
     lr = 2e-4
 
-    ocfg = OM.FluxConfig(**KW)
-    P = OM.init_params(ocfg, seed=3, std=0.05, bias_std=0.02)
+    P = OM.init_params(ocfg, seed=3, std=std, bias_std=0.02)
     mo = oracle_flux(ocfg, P)
     oo = torch.optim.AdamW(mo.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
     mp = FluxTransformer2DModel(FluxConfig(**KW), device=dev)
@@ -99,13 +112,23 @@ def test_train_step_with_mmdit_vs_oracle(tag, over, window):
         diffs.append(abs(v.item() - vo))
     second = [d for ((i, t), d) in zip(new_p, diffs) if i >= a.gradient_accumulation_steps]
     moved = [s for ((i, t), s) in zip(new_p, shifts) if i >= a.gradient_accumulation_steps]
+    if record:
+        import json
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        path = os.path.join("gpurun_out", "r03_depth_parity.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old[record] = dict(blocks=[ocfg.num_layers, ocfg.num_single_layers], max_replayed_logp_diff=max(diffs),
+                           max_after_update=max(second), max_shift_by_update=max(moved), rollout_logp_diff=(lp[fin] - lo[fin]).abs().max().item(),
+                           loss=[rp[0], ro[0]], grad_norm=[rp[1], ro[1]])
+        json.dump(old, open(path, "w"), indent=1)
     assert max(diffs) < 1e-3, diffs                        # the north star's bar, on every replayed pair
-    assert max(second) < 5e-4, second                      # (measured: 1e-6 ... 1.6e-4 after the update)
+    assert max(second) < second_bar, second                # (toy depth, measured: 1e-6 ... 1.6e-4 after the update)
     # the update really moved those log-probs (2e-3 ... 2.5e-2 in the first case, up to 1.2e-3 in the Flash case, whose
     # window sits on the first two steps), and by several times more than the two sides disagree
     assert max(moved) > 1e-3 and max(second) < 0.2 * max(moved), (moved, second)
-    assert rp[0] == pytest.approx(ro[0], rel=0.05)          # logged loss (measured 1.2 % apart)
-    assert rp[1] == pytest.approx(ro[1], rel=0.05)          # grad norm of the last update (measured 0.4 % apart)
+    assert rp[0] == pytest.approx(ro[0], rel=loss_rel)      # logged loss (toy depth: measured 1.2 % apart)
+    assert rp[1] == pytest.approx(ro[1], rel=loss_rel)      # grad norm of the last update (toy depth: 0.4 % apart)
     assert rp[4] == ro[4]                                   # same pairs clipped
 
 

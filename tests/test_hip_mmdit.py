@@ -403,6 +403,58 @@ def test_full_width_blocks_vs_oracle():
     assert worst[0][0] < 5e-2, worst[:8]
 
 
+@pytest.mark.parametrize("nd,ns", [(1, 1), (2, 2), (4, 8)])
+def test_full_width_error_vs_depth(nd, ns):
+    """Forward rel-L2 and parameter-gradient cosine against the CPU oracle at FULL width (d = 3072) for 1+1, 2+2 and 4+8
+    blocks (12 residual blocks, 2.5 B parameters; FLUX.1-dev: 19 + 38), 256 image + 64 text tokens: how the bf16 error
+    compounds with depth.  Numbers go to gpurun_out/r03_depth_parity.json; DESIGN.md section 2 quotes them."""
+    import json
+    import os
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    kw = dict(num_layers=nd, num_single_layers=ns)
+    ocfg = OM.FluxConfig(**kw)
+    P = OM.init_params(ocfg, seed=2, std=0.02, bias_std=0.02)
+    m = FluxTransformer2DModel(FluxConfig(**kw), device="cuda")
+    m.load_state_dict({k: v.cuda() for k, v in P.items()})
+    g = torch.Generator().manual_seed(4)
+    B, hg, wg, L = 1, 16, 16, 64
+    N = hg * wg
+    x = torch.randn(B, N, 64, generator=g)
+    ehs = (0.1 * torch.randn(B, L, 4096, generator=g)).bfloat16()
+    pooled = torch.randn(B, 768, generator=g).bfloat16()
+    ids = torch.zeros(hg, wg, 3)
+    ids[..., 1] += torch.arange(hg)[:, None]
+    ids[..., 2] += torch.arange(wg)[None]
+    ids = ids.reshape(N, 3)
+    tids, t, gd = torch.zeros(L, 3), torch.tensor([0.954]), torch.tensor([3.5]).bfloat16()
+    R = torch.randn(B, N, 64, generator=g)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = OM.forward(Pg, ocfg, x, ehs.float(), t, gd.float(), tids, pooled.float(), ids)
+    (ref * R).sum().backward()
+    m.train()
+    out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
+    fwd = rel_err(out, ref)
+    (out.float() * R.cuda()).sum().backward()
+    dots = nh = no = 0.0
+    worst = 0.0
+    for k in P:
+        gh = m.store.view(m.store.g32, k).float().cpu()
+        go = Pg[k].grad
+        dots += (gh * go).sum().item()
+        nh += gh.pow(2).sum().item()
+        no += go.pow(2).sum().item()
+        worst = max(worst, ((gh - go).norm() / (go.norm() + 1e-9)).item())
+    cos = dots / math.sqrt(nh * no)
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = os.path.join("gpurun_out", "r03_depth_parity.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old[f"fwd_bwd_{nd}+{ns}"] = dict(forward_rel_l2=fwd, grad_cosine=cos, worst_tensor_rel=worst)
+    json.dump(old, open(path, "w"), indent=1)
+    assert fwd < 2e-2, fwd
+    assert cos > 0.998, cos
+    assert worst < 1e-1, worst
+
+
 def test_second_forward_before_backward_is_refused():
     """The training forward keeps its activations in the model's shared workspace: a second grad-enabled forward before the
     first one's backward overwrites them, so that backward must fail loudly instead of returning wrong gradients."""
