@@ -598,7 +598,9 @@ def main(args, reward_function=None, reward_weights=None):
     init_steps = 0
     if args.resume_from_checkpoint:
         init_steps = load_resume_state(args.resume_from_checkpoint, optimizer, lr_scheduler, grpo_states)
-        load_rng_state(args.resume_from_checkpoint, rk)
+        for _ in range(init_steps):                     # the prompts the finished steps consumed (one batch per train step)
+            next(loader)
+        load_rng_state(args.resume_from_checkpoint, rk)  # last: nothing below draws from a generator before the next step does
         main_print(f"--> resumed from {args.resume_from_checkpoint} at step {init_steps}")
     main_print("***** Running training *****")
     main_print(f"  Num examples = {len(train_dataset)}  world size = {ws}  resume step = {init_steps}")

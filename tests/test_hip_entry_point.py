@@ -48,7 +48,7 @@ def _run(flags, tmp):
 def test_main_with_the_launchers_flags_then_resume(tmp_path):
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
     tmp = str(tmp_path)
-    cfg = FluxConfig(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64,
+    cfg = FluxConfig(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=4, joint_attention_dim=64,
                      pooled_projection_dim=32)
     FluxTransformer2DModel(cfg, device="cuda").init_synthetic(seed=5, std=0.05).save_pretrained(os.path.join(tmp, "flux", "transformer"))
     root = os.path.join(tmp, "rl_embeddings")
