@@ -109,12 +109,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    backend = os.environ.get("MGX_DIST_BACKEND", "nccl") if world > 1 else None    # nccl == RCCL on ROCm
+    if world > 1 and backend == "nccl" and a.gpus > torch.cuda.device_count():
+        # fail fast, before any collective: RCCL needs one device per rank (two ranks on one device hang in the communicator
+        # set-up); `MGX_DIST_BACKEND=gloo` is the rehearsal form on a box with fewer GPUs
+        raise SystemExit(f"bench.py: --gpus {a.gpus} over RCCL needs {a.gpus} visible devices, this host has "
+                         f"{torch.cuda.device_count()} (rehearse with MGX_DIST_BACKEND=gloo)")
     local_dev = local_rank % torch.cuda.device_count()      # (== local_rank on a full node; lets a 1-GPU box rehearse N ranks over gloo)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MGX_DIST_BACKEND", "nccl")                            # nccl == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -347,6 +352,18 @@ def main():
                               "note": "grad_norm = norm of the step's last optimizer update, 0.0 when every pair of that "
                                       "chunk is PPO-clipped at clip_range 1e-4 (DESIGN.md section 6)"} if last else None,
                 "roofline": roofline, "cpu_baseline": cpu}
+        # what the collective library saw (so that an N > 1 record answers "did RCCL see N ranks?" by itself) and every
+        # MGX_* environment switch that selects a kernel or a policy in the shipped library: a stale variable is visible here
+        red = getattr(model, "_mgx_grad_reducer", None)
+        line["dist"] = {"backend": (dist.get_backend() if world > 1 else None),
+                        "world_size": (dist.get_world_size() if world > 1 else 1),
+                        "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
+                        "grad_dtype": (getattr(red, "mode", None) if red is not None else os.environ.get("MGX_DP_GRAD_DTYPE", "bf16")) if world > 1 else None,
+                        "overlap": (bool(getattr(red, "overlap", False)) if red is not None else os.environ.get("MGX_DP_OVERLAP", "0") == "1") if world > 1 else None,
+                        "devices_visible": torch.cuda.device_count(),
+                        "note": "measured on this run's ranks only; no 8-GPU number is extrapolated anywhere"}
+        line["config"]["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MGX_")}
+        line["config"]["reward_seed"] = "1234 + 131 * step + rank (SURVEY 8d names 1234 + step; same distribution)"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -145,22 +145,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   int cur = 0;
   // one K/V tile: S^T, online softmax, O^T accumulation.  Kept as a lambda over a compile-time MASK so the full
   // tiles carry no masking selects (hipcc if-converts a runtime "last tile" test into ~200 v_cndmask per tile).
-#ifdef MGX_DIAG_FWD_STAMPS   /* diagnostic build (scratch/ only): where a K/V tile's cycles go; sums land in the LSE buffer */
-  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tlast;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
-#define STAMP(k_)                                                                  \
-  do {                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    unsigned long long now_;                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    tsum[k_] += now_ - tlast;                                                      \
-    tlast = now_;                                                                  \
-  } while (0)
-#else
 #define STAMP(k_) do {} while (0)
-#endif
   auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
     if (t + 1 < ntiles) LOAD_KV(t + 1);
@@ -324,14 +309,6 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntiles) tile(nfull, std::true_type{});
 
-#ifdef MGX_DIAG_FWD_STAMPS
-  if (lane == 0 && g.lse) {
-    // behind the real LSE area [B, H, S] (the diagnostic script allocates the buffer that much larger)
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.lse + (((long)g.B * g.H * g.S + 1) & ~1L)) +
-                              ((long)blockIdx.x * NW + wid) * 8;
-    for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = tsum[k_];
-  }
-#endif
 #undef STAMP
   // ---- finalize: row sum across the two half-waves, normalise, store O[q][h*128 + d]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

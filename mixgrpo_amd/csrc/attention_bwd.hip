@@ -219,22 +219,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" :: "v"(kf[ks]));
   int cur = 0;
-#ifdef MGX_DIAG_DKV_STAMPS   /* diagnostic build (scratch/ only): where a q-tile's cycles go; sums land in the dQ buffer */
-  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(k_)                                                                  \
-  do {                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    unsigned long long now_;                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                             \
-    tsum[k_] += now_ - tlast;                                                      \
-    tlast = now_;                                                                  \
-  } while (0)
-  unsigned long long tlast;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
-#else
 #define STAMP(k_) do {} while (0)
-#endif
   auto tile = [&](int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
     STAMP(0);
@@ -326,12 +311,6 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkv_kernel(BwdArgs g) {
   } else {
     for (int t = 0; t < nqt; ++t) tile(t, std::false_type{});
   }
-#ifdef MGX_DIAG_DKV_STAMPS
-  if (lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.dQ) + ((long)blockIdx.x * 8 + wid) * 8;
-    for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = tsum[k_];
-  }
-#endif
 #undef STAMP
   const int key = key0 + r;
   if (key < g.S) {
@@ -609,9 +588,6 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   const int w64 = w64e ? atoi(w64e) : 1;
   // the generated 64-wide kernels: S % 256 == 0, 32-bit offsets inside a 256-row block of dO, 24-bit row * ldo products
   const bool wide = w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31) && ldo * 2 < (1L << 24) && Sp * 2 < (1L << 24);
-#ifdef MGX_DIAG_DKV_STAMPS
-  attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);
-#else
   if (wide) {
     static bool attr64 = false;
     if (!attr64) {
@@ -625,7 +601,6 @@ extern "C" int mgx_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t
     attn_bwd_dkv_kernel<<<nb, 512, 2 * DKV_STAGE + 65536, st>>>(g);   // + wave-private V fragments
     attn_bwd_dq_kernel<<<nb, 512, 2 * DQ_STAGE, st>>>(g);
   }
-#endif
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -5,16 +5,9 @@
 
 #include <cstdio>
 
-// Timing-only diagnostic switches (-DMGX_TIMING_ONLY_*, -DMGX_GEMM_COMPILER_WAITS) compile kernels whose RESULTS ARE WRONG
-// (they price one part of a kernel by removing it).  They exist only together with -DMGX_DIAGNOSTIC_BUILD, which makes
-// mgx_version() negative: mixgrpo_amd/_lib.py refuses such a library, and mixgrpo_amd/build.py writes it to scratch/ only.
-#if (defined(MGX_TIMING_ONLY_NO_EPI_STORES) || defined(MGX_TIMING_ONLY_NO_EPILOGUE) || defined(MGX_TIMING_ONLY_NO_DMA) ||   \
-     defined(MGX_TIMING_ONLY_NO_FRAG_READS) || defined(MGX_TIMING_ONLY_MFMA32) || defined(MGX_TR_MAP16X4) || defined(MGX_TIMING_ONLY_NO_KTILE_SYNC) || \
-     defined(MGX_TIMING_ONLY_NO_VMCNT) || defined(MGX_TIMING_ONLY_PP_NODMA) || defined(MGX_TIMING_ONLY_PP_NOREADS) || defined(MGX_TIMING_ONLY_NO_BARRIER) || defined(MGX_GEMM_COMPILER_WAITS) ||        \
-     defined(MGX_GEMM_SETPRIO) || defined(MGX_GEMM_WSTAG) || defined(MGX_DIAG_DKV_STAMPS) || defined(MGX_DIAG_PP_STAMPS) || defined(MGX_DIAG_PP_CLOCK) || defined(MGX_DIAG_FWD_STAMPS) || defined(MGX_GEMM_A_AUX) || defined(MGX_GEMM_W_AUX) || defined(MGX_EPI_LAYOUT16)) &&       \
-    !defined(MGX_DIAGNOSTIC_BUILD)
-#error "MGX_TIMING_ONLY_* / MGX_GEMM_COMPILER_WAITS need -DMGX_DIAGNOSTIC_BUILD (python -m mixgrpo_amd.build --diagnostic ...)"
-#endif
+// Diagnostic builds (-DMGX_DIAGNOSTIC_BUILD: mgx_version() < 0, refused by mixgrpo_amd/_lib.py) are written to scratch/ only
+// (mixgrpo_amd/build.py --diagnostic).  The product sources carry no timing-only switches: in-kernel stamps and timing-only
+// variants of the generated kernels are options of their generators (csrc/gen/*.py --diag) built by scratch harnesses.
 
 typedef __bf16 bf16_t;
 typedef uint16_t bf16_raw;  // storage view used on the C ABI

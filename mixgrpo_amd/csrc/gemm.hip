@@ -1,8 +1,8 @@
 // bf16 MFMA GEMM for the MMDiT linears (gfx950):  C[M,N] = epi( A[M,K] @ W[N,K]^T + bias )
 //
 // Both operands are K-contiguous ("NT"): activations [tokens, features] and torch Linear weights [out, in].
-// Two kernels: `gemm_persist_kernel` (256x256x64 tiles, persistent, LDS-DMA staging: every problem with >= 128 such tiles,
-// i.e. all the FLOPs that matter; described at its definition) and `gemm_kernel` for the small problems:
+// Two kernels: `gemm_pp_kernel` (256x256x64 tiles, persistent, LDS-DMA staging, ping-pong K-loop: every problem with >= 128
+// such tiles, i.e. all the FLOPs that matter; described at its definition) and `gemm_kernel` for the small problems:
 // tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16
 // accumulators.  Operands are staged global -> registers -> LDS (issue-early / write-late, one barrier per
 // K-tile, two LDS buffers); the LDS image is [row][64 k] with an XOR swizzle on the 16-byte chunk index
@@ -52,7 +52,7 @@ struct GemmArgs {
   float beta;             // EPI_F32_ACC: C = beta*C + acc
   int rowwise_ok;         // all bf16 side operands are 16-byte addressable: the LDS-staged epilogue may be used
   int span32;             // both operands span < 4 GiB: the persistent kernel's 32-bit DMA source offsets are valid
-  int band;               // tile order of the persistent kernels (set in launch(): rule at gemm_persist_kernel)
+  int band;               // tile order of the persistent kernel (set in launch(): rule at gemm_pp_kernel)
 };
 
 // gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With tanh(u) = 2 s - 1, s = 1 / (1 + e^{-2u}):
@@ -306,12 +306,8 @@ __global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restr
   __shared__ float cs[16][129];
   // tx: 8-column group, ty: 8-row group.  A wave covers 8 x 8 of them (64 columns x 64 rows), so that every load
   // instruction of the wave reads 8 rows x 128 contiguous bytes and every store instruction writes 8 rows x 128 bytes
-  // (with 16 x 4 groups per wave the stores were 64-byte pieces of 16 different rows).  MGX_TR_MAP16X4: the old map (A/B).
-#ifdef MGX_TR_MAP16X4
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-#else
+  // (with 16 x 4 groups per wave the stores were 64-byte pieces of 16 different rows; profiles/r02_transpose_ab.log).
   const int tx = (threadIdx.x & 7) | (((threadIdx.x >> 6) & 1) << 3), ty = ((threadIdx.x >> 3) & 7) | ((threadIdx.x >> 7) << 3);
-#endif
   const int n0 = blockIdx.x * 128 + tx * 8;
   const long m0 = (long)blockIdx.y * 128 + ty * 8;
   uint32_t r[8][4];
@@ -378,16 +374,11 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
 // per-row `if (in range) { load; use; store }` makes hipcc emit branch + load + s_waitcnt vmcnt(0) per row, i.e.
 // serial HBM round trips (vmcnt counts stores too, so each wait also drains the previous row's store): that form
 // cost ~20 us of an 80 us K=3072 tile.
-// (Variant kept for A/B, -DMGX_EPI_LAYOUT16: the lane's four accumulator tiles as 16 CONSECUTIVE features.  Default: tiles
-// t = 0, 1 are features fq*8 .. fq*8+7 and tiles t = 2, 3 the same + 32, so that ONE 16-byte store instruction of the wave
-// writes 64 contiguous bytes per token row -- half a 128-byte line -- instead of four 16-byte pieces 32 bytes apart.)
-#ifdef MGX_EPI_LAYOUT16
-__device__ __forceinline__ int wperm(int p) { return ((p & 15) >> 2) * 16 + (p >> 4) * 4 + (p & 3); }
-__device__ __forceinline__ int lane_feat(int fq, int t) { return fq * 16 + t * 4; }
-#else
+// (The lane's four accumulator tiles: t = 0, 1 are features fq*8 .. fq*8+7 and tiles t = 2, 3 the same + 32, so that ONE 16-byte store instruction of the wave
+// writes 64 contiguous bytes per token row -- half a 128-byte line -- instead of four 16-byte pieces 32 bytes apart, which is
+// what 16 CONSECUTIVE features per lane gave: profiles/r02_ab_gemm_variants.log.)
 __device__ __forceinline__ int wperm(int p) { return (p >> 5) * 32 + ((p & 15) >> 2) * 8 + ((p >> 4) & 1) * 4 + (p & 3); }
 __device__ __forceinline__ int lane_feat(int fq, int t) { return (t >> 1) * 32 + fq * 8 + (t & 1) * 4; }
-#endif
 
 __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
   v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
@@ -621,360 +612,28 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
         if ((EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GATE_RES) && g.aux) {
           char* ab = const_cast<char*>(abase);      // pre-activation / pre-gate branch output for the backward pass
           const uint32_t ao = (uint32_t)r * lda2;
-#ifdef MGX_TIMING_ONLY_NO_EPI_STORES     /* diagnostic build (wrong results): the epilogue's loads and arithmetic without its stores */
-          asm volatile("" :: "v"(y[j][0].x), "v"(y[j][0].y), "v"(y[j][0].z), "v"(y[j][0].w), "v"(y[j][1].x), "v"(y[j][1].y),
-                       "v"(y[j][1].z), "v"(y[j][1].w), "v"(ab), "v"(ao));
-        }
-        asm volatile("" :: "v"(o[jj][0].x), "v"(o[jj][0].y), "v"(o[jj][0].z), "v"(o[jj][0].w), "v"(o[jj][1].x), "v"(o[jj][1].y),
-                     "v"(o[jj][1].z), "v"(o[jj][1].w), "v"(cb), "v"(co));
-#else
           if (nok0) *reinterpret_cast<uint4*>(ab + (ao + c0)) = y[j][0];
           if (nok1) *reinterpret_cast<uint4*>(ab + (ao + c1)) = y[j][1];
         }
         if (nok0) *reinterpret_cast<uint4*>(cb + (co + c0)) = o[jj][0];
         if (nok1) *reinterpret_cast<uint4*>(cb + (co + c1)) = o[jj][1];
-#endif
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Staging: all 160 KiB of LDS as THREE 32 KiB stages for A and TWO for W.  The A pieces of K-tile k+2 and the W pieces of
-// K-tile k+1 are issued in iteration k, W first; the end-of-iteration wait is a counted `vmcnt(4)` that leaves the four A
-// pieces (the youngest) in flight, so the activation operand -- streamed from HBM -- gets two K-tiles of lead and only the
-// weight operand (L2 / Infinity-Cache resident) has to land within one.  Raw s_barrier: __syncthreads() would drain the DMA
-// queue.  (With two 64 KiB stages and vmcnt(0) the per-K-tile rendezvous cost 16-20 %; see DESIGN.md.)  Needs K >= 128.
-template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
-  constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
-  constexpr int WBASE = 3 * TB;                   // LDS: A stages at 0, TB, 2 TB; W stages at 3 TB, 4 TB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
-  const int nwg = tiles_m * tiles_n;
-  const int nkt = g.K / BK;
-  // Tile order: bands of `band` tile rows, column-major inside a band, so the 32 CUs of an XCD work on band x (32 / band)
-  // tiles that share `band` A panels and 32 / band W panels.  The activation operand streams from HBM, the weights sit
-  // in the Infinity Cache: narrow outputs (<= 16 tile columns) take band 1 -- a round is then whole tile rows, every A
-  // panel is fetched once (N = 3072, K = 15360: 1308 -> 1371 TFLOP/s against band 8) -- wider ones band 4 (4 x 8 rounds:
-  // +0.7-1 % against 8 x 4; band 1 would put 32 W panels in a round: -3-4 %).  Few tile ROWS (the wgrad shapes with 3072
-  // output rows): the mirror case, one band of all rows, every W panel once (+1 %).
-  const int band = g.band;                // = tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4), launch()
-  // tile list of this workgroup: the XCD (blockIdx & 7) owns a contiguous range of the banded tile order and its
-  // workgroups take every (gridDim/8)-th tile of it
-  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
-  const int q = nwg >> 3, rem = nwg & 7;
-  const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  const int xend = xbeg + (xcd < rem ? q + 1 : q);
-  int t_lin = xbeg + lane_in_xcd;
-  if (t_lin >= xend) return;
 
-  const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar: LDS-DMA bases stay in SGPRs / M0
-  const int lrow = tid >> 3, lkc = tid & 7;
-  const int src_kc = swz(lrow, lkc);
-  const int wrow = wperm(lrow);                    // W row (inside its 64-row group) that lands in LDS row lrow
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) char gbl_char;
-  // per-lane DMA sources as 32-bit BYTE offsets from the (uniform) operand bases: the host checks both operands
-  // span < 4 GiB.  Half the registers of 64-bit pointers, and the uniform K offset folds into the scalar base.
-  uint32_t ao[4], wo[4];
-  long m0, n0;
-#define TILE_COORDS(tl, M0, N0)                                            \
-  do {                                                                     \
-    const int per_band = band * tiles_n;                                   \
-    const int b0 = (tl) / per_band;                                        \
-    const int rows_in_band = min(band, tiles_m - b0 * band);               \
-    const int in_band = (tl) - b0 * per_band;                              \
-    M0 = (long)(b0 * band + in_band % rows_in_band) * TM;                  \
-    N0 = (long)(in_band / rows_in_band) * TN;                              \
-  } while (0)
-#define TILE_OFFS(M0, N0, AO, WO)                                                          \
-  do {                                                                                     \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
-      long mm = M0 + lrow + k_ * RS;                                                       \
-      if (mm >= g.M) mm = g.M - 1;                                                         \
-      AO[k_] = (uint32_t)((row_off(g.a, mm) + src_kc * 8) * 2);                            \
-      long nn = N0 + k_ * 64 + wrow;                                                       \
-      if (nn >= g.N) nn = g.N - 1;                                                         \
-      WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
-    }                                                                                      \
-  } while (0)
-#ifdef MGX_TIMING_ONLY_NO_DMA             /* diagnostic build (wrong results): no operand staging in the K-loop */
-#define PGLDS_ONE(base, off, off_lds) asm volatile("" :: "v"(off))
-#else
-#ifndef MGX_GEMM_A_AUX
-#define MGX_GEMM_A_AUX 0      /* cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2, sc1 = 16); A/B-tested, see DESIGN.md */
-#endif
-#ifndef MGX_GEMM_W_AUX
-#define MGX_GEMM_W_AUX 0
-#endif
-#define PGLDS_AUX(base, off, off_lds, aux) \
-  __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, aux)
-#define PGLDS_ONE(base, off, off_lds) PGLDS_AUX(base, off, off_lds, 0)
-#endif
-#ifdef MGX_TIMING_ONLY_NO_DMA
-#define PGLDS_A(base, off, off_lds) PGLDS_ONE(base, off, off_lds)
-#define PGLDS_W(base, off, off_lds) PGLDS_ONE(base, off, off_lds)
-#else
-#define PGLDS_A(base, off, off_lds) PGLDS_AUX(base, off, off_lds, MGX_GEMM_A_AUX)
-#define PGLDS_W(base, off, off_lds) PGLDS_AUX(base, off, off_lds, MGX_GEMM_W_AUX)
-#endif
-#define DMA_A(AO, kt_, slot_)                                                                                  \
-  do {                                                                                                        \
-    const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)(kt_) * (BK * 2);                            \
-    const int lb_ = (slot_) * TB + wu * 1024;                                                                 \
-    PGLDS_ONE(ab_, AO[0], lb_); PGLDS_ONE(ab_, AO[1], lb_ + RS * 128); PGLDS_ONE(ab_, AO[2], lb_ + 2 * RS * 128); \
-    PGLDS_ONE(ab_, AO[3], lb_ + 3 * RS * 128);                                                                \
-  } while (0)
-#define DMA_W(WO, kt_, slot_)                                                                                  \
-  do {                                                                                                        \
-    const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)(kt_) * (BK * 2);                            \
-    const int lb_ = WBASE + (slot_) * TB + wu * 1024;                                                         \
-    PGLDS_ONE(wb_, WO[0], lb_); PGLDS_ONE(wb_, WO[1], lb_ + RS * 128); PGLDS_ONE(wb_, WO[2], lb_ + 2 * RS * 128); \
-    PGLDS_ONE(wb_, WO[3], lb_ + 3 * RS * 128);                                                                \
-  } while (0)
-
-  // Fragment reads are inline asm with hand-counted `lgkmcnt` waits.  With LDS-DMA instructions in the loop hipcc's
-  // wait-count pass treats the LDS counter as out of order and turns every wait for a `ds_read` into `lgkmcnt(0)`: the ten
-  // head reads of a K-tile (80 KiB per workgroup, right after the barrier) had to drain completely before the first MFMA,
-  // and reads issued two MFMA groups ahead were drained one group after their issue.  The schedule below is pinned anyway,
-  // so the counts are static: N = number of reads issued after the youngest one the next MFMA needs.
-  s16x8 fa[2][MT], fw[2][NTL];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
-  uint32_t a_ro[2], w_ro[2];                       // lane offsets inside a stage: row, swizzled 16-byte chunk of k-step ks
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    a_ro[ks] = (uint32_t)((wm * 128 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
-    w_ro[ks] = (uint32_t)((wn * 64 + fr) * 128 + (swz(fr, ks * 4 + fq) << 4));
-  }
-#ifdef MGX_TIMING_ONLY_NO_FRAG_READS      /* diagnostic build (wrong results): MFMAs on stale fragment registers */
-#define RD_W(ks, t) asm volatile("" : "+v"(fw[ks][t]))
-#define RD_A(ks, t) asm volatile("" : "+v"(fa[ks][t]))
-#elif defined(MGX_GEMM_COMPILER_WAITS)    /* A/B build: plain loads, hipcc's own (all lgkmcnt(0)) waits */
-#define RD_W(ks, t) fw[ks][t] = *reinterpret_cast<const s16x8*>(smem + (w_ad[ks] - lds0) + (t) * 2048)
-#define RD_A(ks, t) fa[ks][t] = *reinterpret_cast<const s16x8*>(smem + (a_ad[ks] - lds0) + (t) * 2048)
-#else
-#define RD_W(ks, t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ks][t]) : "v"(w_ad[ks]), "n"((t) * 2048))
-#define RD_A(ks, t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[ks][t]) : "v"(a_ad[ks]), "n"((t) * 2048))
-#endif
-#ifdef MGX_GEMM_COMPILER_WAITS
-#define WAIT1(n, x0) do {} while (0)
-#define WAIT2(n, x0, x1) do {} while (0)
-#define WAIT6(n, x0, x1, x2, x3, x4, x5) do {} while (0)
-#else
-#define WAIT1(n, x0) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0))
-#define WAIT2(n, x0, x1) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0), "+v"(x1))
-#define WAIT6(n, x0, x1, x2, x3, x4, x5) \
-  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5))
-#endif
-#define MMA1(ks, i_, j_) \
-  acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0)
-#ifdef MGX_TIMING_ONLY_MFMA32             /* diagnostic build (wrong results): the same fragments and MFMA cycles on half as many, 32x32x16 instructions */
-#define MMA_GROUP(ks, gq)                                                                                  \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_) {                                   \
-      acc16[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][2 * (j_ & 1)], fa[ks][j_], acc16[j_], 0, 0, 0);     \
-      acc16[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][2 * (j_ & 1) + 1], fa[ks][j_], acc16[j_], 0, 0, 0); \
-    }                                                                                                      \
-  } while (0)
-#else
-#define MMA_GROUP(ks, gq)                                                                                  \
-  do {                                                                                                     \
-    PRIO(1);                                                                                               \
-    _Pragma("unroll") for (int j_ = 2 * (gq); j_ < 2 * (gq) + 2; ++j_)                                     \
-      _Pragma("unroll") for (int i_ = 0; i_ < NTL; ++i_)                                                   \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i_], fa[ks][j_], acc[i_][j_], 0, 0, 0); \
-    PRIO(0);                                                                                               \
-  } while (0)
-#endif
-#define PIN() __builtin_amdgcn_sched_barrier(0)
-#ifdef MGX_GEMM_SETPRIO       /* A/B variant: raised wave priority around every 8-MFMA group */
-#define PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define PRIO(x) do {} while (0)
-#endif
-
-  TILE_COORDS(t_lin, m0, n0);
-  TILE_OFFS(m0, n0, ao, wo);
-  // prologue: A K-tiles 0, 1 -> A slots 0, 1; W K-tile 0 -> W slot 0
-  DMA_A(ao, 0, 0);
-  DMA_W(wo, 0, 0);
-  DMA_A(ao, 1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int aslot = 0, wslot = 0;                        // slots holding the K-tile being multiplied
-  while (true) {
-    const int t_next = t_lin + per_xcd_wg;
-    const bool has_next = t_next < xend;
-    long nm0 = 0, nn0 = 0;
-    uint32_t nao[4] = {ao[0], ao[1], ao[2], ao[3]}, nwo[4] = {wo[0], wo[1], wo[2], wo[3]};
-    if (has_next) {
-      TILE_COORDS(t_next, nm0, nn0);
-      TILE_OFFS(nm0, nn0, nao, nwo);
-    }
-    // DMA source sets in use: they switch to the next tile two (A) / one (W) K-tiles before this tile ends
-    uint32_t ca[4] = {ao[0], ao[1], ao[2], ao[3]}, cw[4] = {wo[0], wo[1], wo[2], wo[3]};
-    f32x4 acc[NTL][MT];
-#ifdef MGX_TIMING_ONLY_MFMA32
-    f32x16 acc16[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc16[j][r] = 0.f;
-#else
-#pragma unroll
-    for (int i = 0; i < NTL; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-
-    for (int kt = 0; kt < nkt; ++kt) {
-      const bool a_next = kt + 2 >= nkt, w_next = kt + 1 >= nkt;
-      const int akt = a_next ? kt + 2 - nkt : kt + 2;   // (for the last tile: a harmless re-fetch of its own K-tiles)
-      const int wkt = w_next ? 0 : kt + 1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ca[k] = a_next ? nao[k] : ca[k];
-        cw[k] = w_next ? nwo[k] : cw[k];
-      }
-      const int a_dst = aslot == 0 ? 2 : aslot - 1;     // (aslot + 2) % 3
-      const int w_dst = wslot ^ 1;
-      const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)akt * (BK * 2);
-      const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)wkt * (BK * 2);
-      const int la_ = a_dst * TB + wu * 1024, lw_ = WBASE + w_dst * TB + wu * 1024;
-      const uint32_t sa_u = lds0 + aslot * TB, sw_u = lds0 + WBASE + wslot * TB;
-      const uint32_t a_ad[2] = {sa_u + a_ro[0], sa_u + a_ro[1]}, w_ad[2] = {sw_u + w_ro[0], sw_u + w_ro[1]};
-      // the four W pieces first thing (they must land within this iteration: every cycle of lead counts, +2-7 %)
-#ifdef MGX_GEMM_WSTAG   /* A/B variant: waves 4-7 issue their W pieces behind the second MFMA group instead, so that a SIMD's two
-                           waves are not both stalled in LDS-DMA issue right after the barrier */
-      if (wu < 4) {
-#endif
-      PGLDS_W(wb_, cw[0], lw_); PGLDS_W(wb_, cw[1], lw_ + RS * 128);
-      PGLDS_W(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_W(wb_, cw[3], lw_ + 3 * RS * 128);
-#ifdef MGX_GEMM_WSTAG
-      }
-#endif
-      PIN();
-      // head reads r1..r10, the two the first MFMA needs in front
-      RD_W(0, 0); RD_A(0, 0); RD_W(0, 1); RD_W(0, 2); RD_W(0, 3); RD_A(0, 1);
-      RD_A(0, 2); RD_A(0, 3); RD_A(0, 4); RD_A(0, 5);
-      PIN();
-#ifdef MGX_TIMING_ONLY_MFMA32
-      MMA_GROUP(0, 0);
-#else
-      WAIT2(8, fw[0][0], fa[0][0]); MMA1(0, 0, 0); PIN();
-      WAIT1(7, fw[0][1]); MMA1(0, 1, 0); PIN();
-      WAIT1(6, fw[0][2]); MMA1(0, 2, 0); PIN();
-      WAIT1(5, fw[0][3]); MMA1(0, 3, 0); PIN();
-      WAIT1(4, fa[0][1]); MMA1(0, 0, 1); MMA1(0, 1, 1); MMA1(0, 2, 1); MMA1(0, 3, 1);
-#endif
-      PIN();
-      RD_A(0, 6); RD_A(0, 7);                                           // r11, r12
-      PIN();
-      WAIT2(4, fa[0][2], fa[0][3]);                                     // r7, r8 (r9..r12 may be in flight)
-      MMA_GROUP(0, 1);
-      PIN();
-#ifdef MGX_GEMM_WSTAG
-      if (wu >= 4) {
-        PGLDS_W(wb_, cw[0], lw_); PGLDS_W(wb_, cw[1], lw_ + RS * 128);
-        PGLDS_W(wb_, cw[2], lw_ + 2 * RS * 128); PGLDS_W(wb_, cw[3], lw_ + 3 * RS * 128);
-      }
-      PIN();
-#endif
-      RD_W(1, 0); RD_W(1, 1); RD_W(1, 2); RD_W(1, 3); RD_A(1, 0); RD_A(1, 1);   // r13..r18
-      PIN();
-      WAIT2(8, fa[0][4], fa[0][5]);                                     // r9, r10
-      MMA_GROUP(0, 2);
-      PIN();
-      RD_A(1, 2); RD_A(1, 3);                                           // r19, r20
-      // the four A pieces (two K-tiles of lead) in pairs behind MFMA groups (all eight at the top: 6-9 % slower)
-      PGLDS_A(ab_, ca[0], la_); PGLDS_A(ab_, ca[1], la_ + RS * 128);
-      PIN();
-      WAIT2(8, fa[0][6], fa[0][7]);                                     // r11, r12
-      MMA_GROUP(0, 3);
-      PIN();
-      RD_A(1, 4); RD_A(1, 5);                                           // r21, r22
-      PGLDS_A(ab_, ca[2], la_ + 2 * RS * 128); PGLDS_A(ab_, ca[3], la_ + 3 * RS * 128);
-      PIN();
-      WAIT6(4, fw[1][0], fw[1][1], fw[1][2], fw[1][3], fa[1][0], fa[1][1]);   // r13..r18
-      MMA_GROUP(1, 0);
-      PIN();
-      RD_A(1, 6); RD_A(1, 7);                                           // r23, r24
-      PIN();
-      WAIT2(4, fa[1][2], fa[1][3]);                                     // r19, r20
-      MMA_GROUP(1, 1);
-      PIN();
-      WAIT2(2, fa[1][4], fa[1][5]);                                     // r21, r22
-      MMA_GROUP(1, 2);
-      PIN();
-      WAIT2(0, fa[1][6], fa[1][7]);                                     // r23, r24
-      MMA_GROUP(1, 3);
-      PIN();
-      // everything but the four A pieces issued in this iteration has landed: the next K-tile's W (this iteration) and A
-      // (previous iteration) are complete; all fragment reads of this K-tile have returned (lgkmcnt(0))
-#if defined(MGX_TIMING_ONLY_NO_KTILE_SYNC)  /* diagnostic builds (wrong results) */
-#elif defined(MGX_TIMING_ONLY_NO_VMCNT)
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_s_barrier();
-#elif defined(MGX_TIMING_ONLY_NO_BARRIER)
-      asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#endif
-      aslot = aslot == 2 ? 0 : aslot + 1;
-      wslot ^= 1;
-    }
-    // the epilogue touches no LDS: the next tile's K-loop (whose first K-tile is already resident) follows directly.
-    // Its lane-dependent addressing starts from opaque copies so that none of it is computed before the K-loop and
-    // kept alive across it (the loop runs at the 256-VGPR limit; a reload inside it also drains the DMA queue).
-    int el = lane, ew = wid;
-    asm volatile("" : "+v"(el), "+v"(ew));
-#ifdef MGX_TIMING_ONLY_MFMA32
-#pragma unroll
-    for (int i = 0; i < NTL; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{acc16[j][4 * i], acc16[j][4 * i + 1], acc16[j][4 * i + 2], acc16[j][4 * i + 3]};
-#endif
-#ifdef MGX_TIMING_ONLY_NO_EPILOGUE        /* diagnostic build (wrong results): what the register epilogue costs in situ */
-#pragma unroll
-    for (int i = 0; i < NTL; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) asm volatile("" :: "v"(acc[i][j]));
-#else
-    persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
-#endif
-    if (!has_next) break;
-    t_lin = t_next;
-    m0 = nm0; n0 = nn0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
-  }
-#undef TILE_COORDS
-#undef TILE_OFFS
-#undef PGLDS_ONE
-#undef DMA_A
-#undef DMA_W
-#undef RD_W
-#undef RD_A
-#undef WAIT1
-#undef WAIT2
-#undef WAIT6
-#undef MMA1
-#undef MMA_GROUP
-#undef PIN
-#undef PRIO
-#undef PGLDS_A
-#undef PGLDS_W
-#undef PGLDS_AUX
-}
-
-// ------------------------------------------------------------------------------------------ ping-pong kernel (the default)
-// Same tile, staging depth, tile order and register epilogue as gemm_persist_kernel, different K-loop.  A K-tile is TWO phases
-// of 32 MFMAs per wave, each phase = [load section | barrier | MFMA section | barrier], and the second half of the waves
+// ------------------------------------------------------------------------------------------ persistent ping-pong kernel
+// 256 workgroups (one per CU) x 8 waves walk 256x256x64 tiles.  Staging: all 160 KiB of LDS as THREE 32 KiB stages for A and
+// TWO for W, filled by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled through the per-lane SOURCE address) two K-tiles ahead;
+// raw s_barrier + counted vmcnt (__syncthreads() would drain the DMA queue); the pipeline runs on across output tiles.
+// Tile order: bands of `band` tile rows, column-major inside a band, so the 32 CUs of an XCD work on band x (32 / band) tiles
+// that share `band` A panels and 32 / band W panels.  The activation operand streams from HBM, the weights sit in the
+// Infinity Cache: narrow outputs (<= 16 tile columns) take band 1 -- a round is whole tile rows, every A panel is fetched
+// once -- wider ones band 4; few tile ROWS (wgrad shapes with 3072 output rows): one band of all rows, every W panel once.
+// (Round 1's K-loop -- all eight waves in the same phase -- is kept as text in scratch/gemm_persist_kernel_round1.hip.txt.)
+// The K-loop: a K-tile is TWO phases of 32 MFMAs per wave, each phase = [load section | barrier | MFMA section | barrier], and the second half of the waves
 // (wm = 1: the SIMD partners of the first half) runs ONE barrier behind, so that on every SIMD one wave's MFMA section
 // coincides with its partner's load section (LDS fragment reads + four LDS-DMA pieces): the in-order stalls of DMA issue and
 // fragment reads never hold up a wave's own MFMAs.
@@ -989,7 +648,7 @@ __global__ void __launch_bounds__(512, 2) gemm_persist_kernel(GemmArgs g) {
 // Measured (profiles/r02_pp_clock.log, in-kernel clock = d s_memtime / d s_memrealtime): 2423-2476 shader cycles per K-tile
 // against the matrix pipe's 2048 (83-85 % busy) at a clock the chip holds at 1.71-1.76 GHz under this load; the first
 // version of this loop with FOUR phases of 16 MFMAs (8 barriers per K-tile) ran 2622-2703 cycles at 1.82-1.87 GHz and
-// 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), gemm_persist_kernel 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
+// 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), round 1's lockstep K-loop 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
 template <int EPI>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
@@ -1041,22 +700,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #define PGLDS(base, off, off_lds) \
   __builtin_amdgcn_global_load_lds((gbl_char*)((base) + (off)), (lds_char*)(smem + (off_lds)), 16, 0, 0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
-#ifdef MGX_DIAG_PP_STAMPS    /* diagnostic build (scratch/ only): cycles per [section + barrier wait], summed per wave, into g.aux */
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  int tsec = 0;
-#define BAR()                                                                        \
-  do {                                                                               \
-    PIN(); __builtin_amdgcn_s_barrier(); PIN();                                      \
-    unsigned long long now_;                                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory");   \
-    PIN();                                                                           \
-    if (tlast) tsum[tsec] += now_ - tlast;                                           \
-    tlast = now_;                                                                    \
-    tsec = (tsec + 1) & 7;                                                           \
-  } while (0)
-#else
 #define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
-#endif
 
   uint32_t a_ro[2], w_ro[2];
 #pragma unroll
@@ -1068,21 +712,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #define LDW(ks, i) (*reinterpret_cast<const s16x8*>(smem + sw_ + w_ro[ks] + (i) * 2048))
 #define MMA(i_, j_, W_, A_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_, A_, acc[i_][j_], 0, 0, 0)
 
-#ifdef MGX_TIMING_ONLY_PP_NODMA      /* diagnostic builds: WRONG results, timing only */
-#define PGLDS_K(base, off, off_lds) do { } while (0)
-#else
 #define PGLDS_K PGLDS
-#endif
-#ifdef MGX_TIMING_ONLY_PP_NOREADS
-#define LDA_K(ks, j) faA[ks][(j) & 3]
-#define LDW_K(ks, i) faA[ks][(i) & 3]
-#else
 #define LDA_K LDA
 #define LDW_K LDW
-#endif
-#ifdef MGX_DIAG_PP_CLOCK      /* diagnostic build: shader cycles and 100 MHz ticks of the whole workgroup, into g.aux */
-  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
   TILE_COORDS(t_lin, m0, n0);
   TILE_OFFS(m0, n0, ao, wo);
   {  // prologue: A K-tiles 0, 1 -> A slots 0, 1; W K-tiles 0, 1 -> W slots 0, 1
@@ -1188,19 +820,6 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
     for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
   }
   if (!late) __builtin_amdgcn_s_barrier();         // matches the late half's last barrier
-#ifdef MGX_DIAG_PP_CLOCK
-  if (EPI == EPI_BIAS && g.aux && tid == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.aux) + (long)blockIdx.x * 2;
-    dbg[0] = __builtin_amdgcn_s_memtime() - clk0;
-    dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-  }
-#endif
-#ifdef MGX_DIAG_PP_STAMPS
-  if (EPI == EPI_BIAS && g.aux && lane == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.aux) + ((long)blockIdx.x * 8 + wid) * 8;
-    for (int k_ = 0; k_ < 8; ++k_) dbg[k_] = tsum[k_];
-  }
-#endif
 #undef TILE_COORDS
 #undef TILE_OFFS
 #undef PGLDS
@@ -1230,18 +849,15 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
-  // MGX_GEMM_MODE (A/B and debugging): 0 forces the 128x128 kernel everywhere, 6 the persistent kernel of round 1 in
-  // place of the ping-pong kernel
+  // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    if (mode == 6) gemm_persist_kernel<EPI><<<grid, 512, 163840, st>>>(g);
-    else gemm_pp_kernel<EPI><<<grid, 512, 163840, st>>>(g);
+    gemm_pp_kernel<EPI><<<grid, 512, 163840, st>>>(g);
   } else {
     gemm_kernel<EPI><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }

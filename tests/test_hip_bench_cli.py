@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 from helpers import free_port
 
@@ -51,6 +52,23 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3          # both ranks' images over the max time
     assert j["cpu_baseline"] is None                                                   # reported at N = 1 only
     assert j["last_step"]["loss"] == j["last_step"]["loss"]
+    # the line says by itself what the collective library saw
+    d = j["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["rccl_version"] is None and d["grad_dtype"] in ("bf16", "fp32")
+    assert d["overlap"] in (True, False) and j["config"]["env_switches"].get("MGX_DIST_BACKEND") == "gloo"
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """`--gpus N` over RCCL with fewer than N visible devices must fail fast with a clear message, before any collective
+    (two RCCL ranks on one device hang in the communicator set-up)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("MGX_DIST_BACKEND",)}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2",
+                        "--workload", "tiny_256_T8_W2_G4", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the devices")
+    assert r.returncode != 0 and "needs 2 visible devices" in (r.stderr + r.stdout)
 
 
 def test_bench_launches_its_own_ranks():
