@@ -341,29 +341,47 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
 #include "attn_fwd64_body.inc"
 
 __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(AttnArgs g) {
+  // Persistent: the blocks (batch, head, q-tile) are cut into 8 contiguous ranges, one per XCD (blockIdx & 7 under round-robin
+  // dispatch: speed only); workgroup j of an XCD takes blocks lo + j, lo + j + stride, ...  (stride = workgroups per XCD), so the
+  // XCD's workgroups work on neighbouring q-tiles of the same heads at the same time and share their K / V in L2.  The next
+  // block's first tiles and Q fragments are fetched during the current block's last iteration.
   const int nq = g.S >> 8;
-  const int nwg = nq * g.H * g.B;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  const long nblk = (long)nq * g.H * g.B;
+  const int G = gridDim.x, w = blockIdx.x;
+  int first, count, stride;
+  if ((G & 7) == 0) {
+    const int x = w & 7, j = w >> 3;
+    stride = G >> 3;
+    const long lo = x * nblk / 8, hi = (x + 1) * nblk / 8;
+    first = (int)(lo + j);
+    count = first < hi ? (int)((hi - first + stride - 1) / stride) : 0;
+  } else {
+    stride = G;
+    first = w;
+    count = first < nblk ? (int)((nblk - first + stride - 1) / stride) : 0;
   }
-  const int qt = bid % nq;
-  const int bh = bid / nq;
+  if (count <= 0) return;
+  const int qt = first % nq;
+  const int bh = first / nq;
   const int b = bh / g.H, hh = bh - b * g.H;
   const unsigned long long qp = (unsigned long long)(g.Q + ((long)bh * g.S + qt * 256) * HD);
   const unsigned long long kp = (unsigned long long)(g.K + (long)bh * g.S * HD);
   const unsigned long long vp = (unsigned long long)(g.Vt + (long)bh * HD * g.Sp);
+  const unsigned long long ob = (unsigned long long)g.O;
   const unsigned long long op = (unsigned long long)(g.O + (long)b * g.o_bstride + (long)(qt * 256) * g.ldo + hh * HD);
   const unsigned long long lp = g.lse ? (unsigned long long)(g.lse + (long)bh * g.S + qt * 256) : 0ull;
   const int ntiles = g.S >> 6;
+  const int ostep = (int)(g.ldo * 512);                       // bytes of 256 rows of O
   asm volatile(ATTN_FWD64_BODY
                :
                : [tid] "v"(threadIdx.x), [q_lo] "s"((unsigned)qp), [q_hi] "s"((unsigned)(qp >> 32)), [k_lo] "s"((unsigned)kp),
                  [k_hi] "s"((unsigned)(kp >> 32)), [v_lo] "s"((unsigned)vp), [v_hi] "s"((unsigned)(vp >> 32)),
                  [o_lo] "s"((unsigned)op), [o_hi] "s"((unsigned)(op >> 32)), [l_lo] "s"((unsigned)lp),
                  [l_hi] "s"((unsigned)(lp >> 32)), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e),
-                 [nloop] "s"((ntiles - 2) >> 1), [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128)
+                 [nloop] "s"((ntiles - 2) >> 1), [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128),
+                 [nblk] "s"(count), [qt0] "s"(qt), [hh0] "s"(hh), [b0] "s"(b), [nq] "s"(nq), [nh] "s"(g.H), [kstep] "s"(g.S * 256),
+                 [ostep] "s"(ostep), [obs] "s"((int)(g.o_bstride * 2)), [ob_lo] "s"((unsigned)ob), [ob_hi] "s"((unsigned)(ob >> 32)),
+                 [sq] "s"(stride % nq), [dbh] "s"(stride / nq), [qstride] "s"(stride * 65536), [lstride] "s"(stride * 1024)
                : ATTN_FWD64_CLOBBERS);
 }
 
@@ -386,13 +404,14 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   static const int ovl = getenv("MGX_ATTN_OVL") ? atoi(getenv("MGX_ATTN_OVL")) : 1;
   const char* w64e = getenv("MGX_ATTN_W64");   // read per call: tests switch kernels inside one process
   const int w64 = w64e ? atoi(w64e) : 1;
-  if (w64 && S % 256 == 0 && Sp == S && ldo * 2 * 256 < (1L << 31)) {
+  if (w64 && S % 256 == 0 && Sp == S && (long)S * ldo * 2 < (1L << 31) && o_bstride * 2 < (1L << 31) && (long)S * 256 < (1L << 31)) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       attr = true;
     }
-    attn_fwd64_kernel<<<(S / 256) * H * B, 256, 65536, st>>>(g);
+    const long nblk = (long)(S / 256) * H * B;
+    attn_fwd64_kernel<<<nblk >= 256 ? 256 : (int)nblk, 256, 65536, st>>>(g);
     MGX_CHECK_LAUNCH();
     return MGX_OK;
   }

@@ -68,9 +68,11 @@ sKT, sVT = 71, 72         # byte offsets of the next K / V^T tiles to fetch
 sTMP = 73
 sQ, sK, sV, sO, sL = 74, 76, 78, 80, 82
 sSP2, sLDO2, sCS, sNLOOP, sKMAX, sVMAX = 84, 85, 86, 87, 88, 89
-sRET = 90                 # pair
+sRET = 90                 # pair: diagnostic stamps; the K(1) prefetch pointer of the next block
 sDBG = 92                 # pair (diagnostic builds)
-S_FIRST, S_LAST = 64, 95
+sLEFT, sQT, sHH, sADV, sWRAP = 94, 95, 96, 97, 98       # block loop: blocks left, (q-tile, head) of the block, flags
+sQTN, sBB = 84, 85               # next q-tile, batch (sSP2 / sLDO2's registers: those are read by the address set-up only)
+S_FIRST, S_LAST = 64, 99
 
 K_BASE, V_BASE = 0, 32768
 SLOT = 16384
@@ -160,11 +162,11 @@ def ds_read_v(n, slot):
     return f"ds_read_b128 {vr(VF + 4 * n, 4)}, {v(VA + sidx)} offset:{slot * SLOT + dt * 4096}"   # V_BASE is in the address
 
 
-def dma_piece(kind, p, slot):
+def dma_piece(kind, p, slot, ptr=None):
     """(m0 write, load) of piece p (0..3) of this wave's quarter of a K ('k') or V^T ('v') tile."""
     base = (K_BASE if kind == "k" else V_BASE) + slot * SLOT + p * 1024
     src = (KS if kind == "k" else VS) + p
-    ptr = sKP if kind == "k" else sVP
+    ptr = ptr if ptr is not None else (sKP if kind == "k" else sVP)
     return (f"s_add_i32 m0, {s(sWOFF)}, {base}", f"global_load_lds_dwordx4 {v(src)}, {sr(ptr, 2)}")
 
 
@@ -177,6 +179,57 @@ def dma_setup():
 def dma_advance():
     return [f"s_add_u32 {s(sKT)}, {s(sKT)}, {SLOT}", f"s_min_u32 {s(sKT)}, {s(sKT)}, {s(sKMAX)}",
             f"s_add_u32 {s(sVT)}, {s(sVT)}, 128", f"s_min_u32 {s(sVT)}, {s(sVT)}, {s(sVMAX)}"]
+
+
+def block_advance_loads():
+    """Top of a block's last iteration: Q / K / V^T pointers of the workgroup's NEXT block -- `stride` blocks further in the
+    (batch, head, q-tile) order, so that the workgroups of an XCD work on neighbouring q-tiles of the same heads at the same
+    time (K / V shared in L2); the workgroup's last block stays where it is -- and the pointers of its first three tiles."""
+    return [f"s_cmp_gt_u32 {s(sLEFT)}, 1", f"s_cselect_b32 {s(sADV)}, 1, 0",
+            f"s_mul_i32 {s(sTMP)}, {s(sADV)}, %[qstride]",                        # stride q-tiles of Q (256 rows x 256 bytes each)
+            f"s_add_u32 {s(sQ)}, {s(sQ)}, {s(sTMP)}", f"s_addc_u32 {s(sQ + 1)}, {s(sQ + 1)}, 0",
+            f"s_mul_i32 {s(sTMP)}, {s(sADV)}, %[sq]", f"s_add_u32 {s(sQTN)}, {s(sQT)}, {s(sTMP)}",    # q-tile + stride % nq
+            f"s_mul_i32 {s(sWRAP)}, {s(sADV)}, %[dbh]",                           # heads advanced: stride / nq ...
+            f"s_cmp_ge_u32 {s(sQTN)}, %[nq]", f"s_cselect_b32 {s(sTMP)}, %[nq], 0",
+            f"s_sub_u32 {s(sQTN)}, {s(sQTN)}, {s(sTMP)}", f"s_cmp_lg_u32 {s(sTMP)}, 0",
+            f"s_addc_u32 {s(sWRAP)}, {s(sWRAP)}, 0",                              # ... + 1 when the q-tile index wrapped
+            f"s_mul_i32 {s(sTMP)}, {s(sWRAP)}, %[kstep]",                         # per head: S rows of K, 128 rows of V^T
+            f"s_add_u32 {s(sK)}, {s(sK)}, {s(sTMP)}", f"s_addc_u32 {s(sK + 1)}, {s(sK + 1)}, 0",
+            f"s_add_u32 {s(sV)}, {s(sV)}, {s(sTMP)}", f"s_addc_u32 {s(sV + 1)}, {s(sV + 1)}, 0",
+            f"s_mov_b32 {s(sKP)}, {s(sK)}", f"s_mov_b32 {s(sKP + 1)}, {s(sK + 1)}",
+            f"s_mov_b32 {s(sVP)}, {s(sV)}", f"s_mov_b32 {s(sVP + 1)}, {s(sV + 1)}",
+            f"s_add_u32 {s(sRET)}, {s(sK)}, {SLOT}", f"s_addc_u32 {s(sRET + 1)}, {s(sK + 1)}, 0",
+            f"s_mov_b32 {s(sKT)}, {2 * SLOT}", f"s_mov_b32 {s(sVT)}, 128"]        # the next block's iteration 0 fetches K(2), V^T(1)
+
+
+def block_advance_stores(A):
+    """Behind the epilogue: (batch, head, q-tile) of the next block, its O / lse pointers; one block less to go."""
+    A.e(f"s_mov_b32 {s(sQT)}, {s(sQTN)}")
+    A.e(f"s_add_u32 {s(sHH)}, {s(sHH)}, {s(sWRAP)}")
+    A.e(f"s_cmp_ge_u32 {s(sHH)}, %[nh]")
+    A.e(f"s_cselect_b32 {s(sTMP)}, %[nh], 0")
+    A.e(f"s_sub_u32 {s(sHH)}, {s(sHH)}, {s(sTMP)}")
+    A.e(f"s_cmp_lg_u32 {s(sTMP)}, 0")
+    A.e(f"s_addc_u32 {s(sBB)}, {s(sBB)}, 0")
+    # O = base + batch * (bytes per batch) + q-tile * (bytes of 256 rows) + head * 256
+    A.e(f"s_mul_i32 {s(sO)}, {s(sBB)}, %[obs]")
+    A.e(f"s_mul_hi_u32 {s(sO + 1)}, {s(sBB)}, %[obs]")
+    A.e(f"s_mul_i32 {s(sTMP)}, {s(sQT)}, %[ostep]")
+    A.e(f"s_add_u32 {s(sO)}, {s(sO)}, {s(sTMP)}")
+    A.e(f"s_addc_u32 {s(sO + 1)}, {s(sO + 1)}, 0")
+    A.e(f"s_lshl_b32 {s(sTMP)}, {s(sHH)}, 8")
+    A.e(f"s_add_u32 {s(sO)}, {s(sO)}, {s(sTMP)}")
+    A.e(f"s_addc_u32 {s(sO + 1)}, {s(sO + 1)}, 0")
+    A.e(f"s_add_u32 {s(sO)}, {s(sO)}, %[ob_lo]")
+    A.e(f"s_addc_u32 {s(sO + 1)}, {s(sO + 1)}, %[ob_hi]")
+    nol = A.new_label("nolnext")
+    A.e(f"s_cmp_eq_u64 {sr(sL, 2)}, 0")
+    A.e(f"s_cbranch_scc1 {nol}")
+    A.e(f"s_mul_i32 {s(sTMP)}, {s(sADV)}, %[lstride]")
+    A.e(f"s_add_u32 {s(sL)}, {s(sL)}, {s(sTMP)}")
+    A.e(f"s_addc_u32 {s(sL + 1)}, {s(sL + 1)}, 0")
+    A.label(nol)
+    A.e(f"s_sub_u32 {s(sLEFT)}, {s(sLEFT)}, 1")
 
 
 def softmax_gaps(ch, ngaps=32):
@@ -281,11 +334,11 @@ def fixup(A, ch, back):
 TIMING_ONLY = set()        # diagnostic variants (wrong results; scratch harness only): "nodma", "nolds", "novalu", "nobarrier"
 
 
-def segment(A, mfmas, valu_gaps, valu_tail, lds=None, dma=None, pre=None, waits=None):
+def segment(A, mfmas, valu_gaps, valu_tail, lds=None, dma=None, pre=None, waits=None, extra=None):
     """Emit one segment: per gap [wait] MFMA, the gap's VALU slice, at most one LDS read, at most one DMA piece.
 
     lds: {gap: instr}; dma: {gap: (m0 write, load)}; waits: {gap: 's_waitcnt ...'} placed in front of the gap's MFMA."""
-    lds, dma, waits = lds or {}, dma or {}, waits or {}
+    lds, dma, waits, extra = lds or {}, dma or {}, waits or {}, extra or {}
     if "nodma" in TIMING_ONLY:
         dma = {}
     if "nolds" in TIMING_ONLY:
@@ -311,6 +364,8 @@ def segment(A, mfmas, valu_gaps, valu_tail, lds=None, dma=None, pre=None, waits=
             A.e(x)
         if g in lds:
             A.e(lds[g])
+        for x in extra.get(g, []):
+            A.e(x)
     for x in valu_tail:
         A.e(x)
 
@@ -325,7 +380,19 @@ def iteration(A, par, fixups, first=False, last=False):
     pre = []
     if first:
         pre = max_prefix(CA)
-    dma, lds = {}, {}
+    dma, lds, extra1, extra2 = {}, {}, {}, {}
+    if last:
+        # the NEXT block's first tiles and Q fragments (the same block again when this is the workgroup's last: unused):
+        # K(0), V^T(0) -> slot 0 and K(1) -> slot 1 are free since the barrier behind iteration nt-2; Q_A since then too, Q_B
+        # after its last S^T product in this segment
+        pre = block_advance_loads() + pre
+        pieces = ([dma_piece("k", p, 0) for p in range(4)] + [dma_piece("v", p, 0) for p in range(4)] +
+                  [dma_piece("k", p, 1, ptr=sRET) for p in range(4)])
+        for j, pc in enumerate(pieces):
+            dma[j] = pc
+        for ks in range(8):
+            extra1[12 + ks] = [f"global_load_dwordx4 {ar(CA.Q + 4 * ks, 4)}, {v(QOFF_A)}, {sr(sQ, 2)} offset:{32 * ks}"]
+            extra2[ks] = [f"global_load_dwordx4 {ar(CB.Q + 4 * ks, 4)}, {v(QOFF_B)}, {sr(sQ, 2)} offset:{32 * ks}"]
     if not last:
         pre = dma_setup() + pre
         pieces = [dma_piece("k", p, par) for p in range(4)] + [dma_piece("v", p, 1 - par) for p in range(4)]
@@ -336,7 +403,7 @@ def iteration(A, par, fixups, first=False, last=False):
     for n in range(16):
         lds[(n if first else 8 + n)] = ds_read_v(n, par)
     A.c("---- segment 1")
-    segment(A, mf, vg, vt, lds=lds, dma=dma, pre=pre)
+    segment(A, mf, vg, vt, lds=lds, dma=dma, pre=pre, extra=extra1)
     end_of_softmax(A, CA, fixups, first)
     # ---------------- segment 2: MFMA chain A (P V of tile i, S^T of tile i+1), softmax chain B
     mf = [mfma_pv(CA, n) for n in range(16)] + ([] if last else [mfma_qk(CA, n) for n in range(16)])
@@ -349,7 +416,7 @@ def iteration(A, par, fixups, first=False, last=False):
         waits[16] = "s_waitcnt lgkmcnt(8)"
         waits[24] = "s_waitcnt lgkmcnt(0)"
     A.c("---- segment 2")
-    segment(A, mf, vg, vt, lds=lds, pre=pre, waits=waits)
+    segment(A, mf, vg, vt, lds=lds, pre=pre, waits=waits, extra=extra2)
     end_of_softmax(A, CB, fixups, first)
     if not last:
         A.e("s_waitcnt vmcnt(0)")                           # this iteration's K(i+2), V^T(i+1) pieces
@@ -442,35 +509,43 @@ def prologue(A):
     A.e(f"s_lshl_b32 {s(sTMP)}, {s(sLDO2)}, 5")
     A.e(f"v_add_u32 {v(OOFF_B)}, {s(sTMP)}, {v(OOFF_A)}")
     A.e(f"v_lshlrev_b32 {v(LOFF)}, 2, {t0}")
-    A.c("first tiles: K(0), V^T(0) -> slot 0, K(1) -> slot 1")
-    A.e(f"s_mov_b32 {s(sKT)}, 0")
-    A.e(f"s_mov_b32 {s(sVT)}, 0")
-    for x in dma_setup():
+    A.c("block loop state; the first block's tiles K(0), V^T(0) -> slot 0, K(1) -> slot 1 and its Q fragments")
+    A.e(f"s_mov_b32 {s(sLEFT)}, %[nblk]")
+    A.e(f"s_mov_b32 {s(sQT)}, %[qt0]")
+    A.e(f"s_mov_b32 {s(sHH)}, %[hh0]")
+    A.e(f"s_mov_b32 {s(sBB)}, %[b0]")
+    for x in (f"s_mov_b32 {s(sKP)}, {s(sK)}", f"s_mov_b32 {s(sKP + 1)}, {s(sK + 1)}",
+              f"s_mov_b32 {s(sVP)}, {s(sV)}", f"s_mov_b32 {s(sVP + 1)}, {s(sV + 1)}",
+              f"s_add_u32 {s(sRET)}, {s(sK)}, {SLOT}", f"s_addc_u32 {s(sRET + 1)}, {s(sK + 1)}, 0",
+              f"s_mov_b32 {s(sKT)}, {2 * SLOT}", f"s_mov_b32 {s(sVT)}, 128"):
         A.e(x)
-    for kind, slot in (("k", 0), ("v", 0)):
-        for p in range(4):
-            m0w, ld = dma_piece(kind, p, slot)
-            A.e(m0w)
-            A.e("s_nop 0")
-            A.e(ld)
-    A.e(f"s_mov_b32 {s(sKT)}, {SLOT}")
-    A.e(f"s_mov_b32 {s(sVT)}, 128")
-    for x in dma_setup():
-        A.e(x)
-    for p in range(4):
-        m0w, ld = dma_piece("k", p, 1)
-        A.e(m0w)
+    for pc in ([dma_piece("k", p, 0) for p in range(4)] + [dma_piece("v", p, 0) for p in range(4)] +
+               [dma_piece("k", p, 1, ptr=sRET) for p in range(4)]):
+        A.e(pc[0])
         A.e("s_nop 0")
-        A.e(ld)
-    A.e(f"s_mov_b32 {s(sKT)}, {2 * SLOT}")          # next fetches: K(2), V^T(1)
+        A.e(pc[1])
     A.c("Q fragments (B operand of S^T = K Q^T): Q[row][16 ks + 8 h ..]")
     for ch, off in ((CA, QOFF_A), (CB, QOFF_B)):
         for ks in range(8):
             A.e(f"global_load_dwordx4 {ar(ch.Q + 4 * ks, 4)}, {v(off)}, {sr(sQ, 2)} offset:{32 * ks}")
-    A.c("O = 0")
+    A.e("s_waitcnt vmcnt(0)")
+
+
+def block_start(A):
+    """Every block: O = 0, the block's first tiles (fetched during the previous block's last iteration, or by the prologue)
+    have landed -- the previous block's O / lse stores, the youngest entries of the vector-memory queue, stay in flight --,
+    K(0) fragments, S^T of chain A."""
+    A.c("================ block start")
     for i in range(128):
         A.e(f"v_accvgpr_write_b32 {a(i)}, 0")
-    A.e("s_waitcnt vmcnt(0)")
+    w16, go = A.new_label("w16"), A.new_label("wgo")
+    A.e(f"s_cmp_eq_u64 {sr(sL, 2)}, 0")
+    A.e(f"s_cbranch_scc1 {w16}")
+    A.e("s_waitcnt vmcnt(18)")                       # 16 O stores + 2 lse stores of the previous block may still be in flight
+    A.e(f"s_branch {go}")
+    A.label(w16)
+    A.e("s_waitcnt vmcnt(16)")
+    A.label(go)
     A.e("s_barrier")
     for n in range(16):
         A.e(ds_read_k(n, 0))
@@ -522,7 +597,7 @@ def epilogue(A):
                 A.e(f"v_permlane32_swap_b32 {v(E)}, {v(E + 2)}")
                 A.e(f"v_permlane32_swap_b32 {v(E + 1)}, {v(E + 3)}")
                 A.e(f"global_store_dwordx4 {v(ooff)}, {vr(E, 4)}, {sr(sO, 2)} offset:{64 * dt + 16 * g}")
-    A.e("s_waitcnt vmcnt(0)")
+    # (no vmcnt(0): the wave ends with its stores in flight, the CU takes the next workgroup meanwhile)
 
 
 def stamp(A, k):
@@ -546,6 +621,9 @@ def generate(diag=False):
         A.e(f"v_lshlrev_b32 {v(DBG_OFF)}, 6, {v(DBG_OFF)}")         # 64 bytes of stamps per wave
         stamp(A, 0)
     prologue(A)
+    block = A.new_label("block")
+    A.label(block)
+    block_start(A)
     if diag:
         stamp(A, 1)
     iteration(A, 0, fixups, first=True)
@@ -568,6 +646,7 @@ def generate(diag=False):
     if diag:
         stamp(A, 4)
     epilogue(A)
+    block_advance_stores(A)
     if diag:
         stamp(A, 5)
         A.e(f"s_memrealtime {sr(sRET, 2)}")
@@ -578,6 +657,9 @@ def generate(diag=False):
         A.e(f"global_store_dwordx2 {v(DBG_OFF)}, {vr(DBG_LO, 2)}, {sr(sDBG, 2)} offset:48")
         A.e("s_mov_b64 exec, -1")
         A.e("s_waitcnt vmcnt(0)")
+    else:
+        A.e(f"s_cmp_lg_u32 {s(sLEFT)}, 0")
+        A.e(f"s_cbranch_scc1 {block}")
     end = A.new_label("end")
     A.e(f"s_branch {end}")
     A.c("================ out-of-line rescale fix-ups")

@@ -28,7 +28,10 @@ fwd64_diag_kernel(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint
                  [o_lo] "s"((unsigned)op), [o_hi] "s"((unsigned)(op >> 32)), [l_lo] "s"(0u), [l_hi] "s"(0u), [sp2] "s"(S * 2),
                  [ldo2] "s"((int)(ldo * 2)), [cs] "s"(scale_log2e), [nloop] "s"((ntiles - 2) >> 1),
                  [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128), [d_lo] "s"((unsigned)dp),
-                 [d_hi] "s"((unsigned)(dp >> 32))
+                 [d_hi] "s"((unsigned)(dp >> 32)), [nblk] "s"(1), [qt0] "s"(qt), [hh0] "s"(hh), [b0] "s"(b), [nq] "s"(nq), [nh] "s"(H),
+                 [kstep] "s"(S * 256), [ostep] "s"((int)(ldo * 512)), [obs] "s"((int)(o_bstride * 2)),
+                 [ob_lo] "s"((unsigned)(unsigned long long)O), [ob_hi] "s"((unsigned)((unsigned long long)O >> 32)), [sq] "s"(0),
+                 [dbh] "s"(0), [qstride] "s"(0), [lstride] "s"(0)
                : ATTN_FWD64_CLOBBERS);
 }
 extern "C" int fwd64_diag(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, unsigned long long* dbg, int B,

@@ -357,6 +357,9 @@ class Machine:
     def i_s_cselect_b32(self, w, ins, o):
         self._sdst(w, o[0], self.ssrc(w, o[1]) if w.scc else self.ssrc(w, o[2]))
 
+    def i_s_cmp_gt_u32(self, w, ins, o):
+        w.scc = int(self.ssrc(w, o[0]) > self.ssrc(w, o[1]))
+
     def i_s_cmp_ge_u32(self, w, ins, o):
         w.scc = int(self.ssrc(w, o[0]) >= self.ssrc(w, o[1]))
 
@@ -375,6 +378,9 @@ class Machine:
         a_, b_ = self.ssrc(w, o[1]), self.ssrc(w, o[2])
         w.scc = 1 if a_ <= b_ else 0
         self._sdst(w, o[0], min(a_, b_))
+
+    def i_s_mul_hi_u32(self, w, ins, o):
+        self._sdst(w, o[0], (self.ssrc(w, o[1]) * self.ssrc(w, o[2])) >> 32)
 
     def i_s_mul_i32(self, w, ins, o):
         self._sdst(w, o[0], self.ssrc(w, o[1]) * self.ssrc(w, o[2]))

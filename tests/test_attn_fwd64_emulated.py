@@ -25,37 +25,55 @@ def _f32(h):
     return (h.astype(np.uint32) << 16).view(np.float32)
 
 
-def _emulate(S, mode, order, seed=0, spike=False, qt=0, with_lse=True):
+def _emulate(S, mode, order, seed=0, spike=False, qt=0, with_lse=True, B=1, H=1, first=None, nblk=1, stride=1):
+    """One workgroup walking `nblk` (batch, head, q-tile) blocks `stride` apart, starting at linear block `first` (default:
+    q-tile `qt` of the single head).  O is [B, S, H * 128 + 64] with this tensor's columns starting at element 32."""
     rng = np.random.default_rng(seed)
-    q, k, v = (rng.standard_normal((S, 128)).astype(np.float32) for _ in range(3))
+    nq = S // 256
+    first = qt if first is None else first
+    q, k, v = (rng.standard_normal((B * H, S, 128)).astype(np.float32) for _ in range(3))
     if spike:    # two keys that outscore their query's first-tile maximum by far more than 2^40: the rescale fix-up must run
-        k[200] = 8 * q[qt * 256 + 70]
-        k[S - 3] = 6 * q[qt * 256 + 100]
+        k[0, 200] = 8 * q[0, qt * 256 + 70]
+        k[0, S - 3] = 6 * q[0, qt * 256 + 100]
     Q, K = _bf16(q), _bf16(k)
-    Vt = np.ascontiguousarray(_bf16(v).T)
-    ldo = 256                                   # two heads wide: this head's columns are 32..159 (byte offset 64)
-    O = np.zeros((S, ldo), np.uint16)
-    lse = np.full(S, -7.0, np.float32)
+    Vt = np.ascontiguousarray(_bf16(v).transpose(0, 2, 1))
+    ldo = H * 128 + 64                          # this tensor's head columns are 32 .. 32 + H * 128 (byte offset 64)
+    O = np.zeros((B, S, ldo), np.uint16)
+    lse = np.full((B * H, S), -7.0, np.float32)
     nt, scale = S // 64, 1 / math.sqrt(128)
-    inputs = dict(tid=np.arange(256).reshape(4, 64), q=("ptr", "Q", qt * 256 * 256), k=("ptr", "K", 0), v=("ptr", "V", 0),
-                  o=("ptr", "O", qt * 256 * ldo * 2 + 64), l=("ptr", "L", qt * 256 * 4), sp2=S * 2, ldo2=ldo * 2,
+    bh0, qt0 = first // nq, first % nq
+    b0, hh0 = bh0 // H, bh0 % H
+    ostep = ldo * 512
+    inputs = dict(tid=np.arange(256).reshape(4, 64), q=("ptr", "Q", (bh0 * S + qt0 * 256) * 256), k=("ptr", "K", bh0 * S * 256),
+                  v=("ptr", "V", bh0 * S * 256), o=("ptr", "O", (b0 * S * ldo + qt0 * 256 * ldo + hh0 * 128) * 2 + 64),
+                  l=("ptr", "L", (bh0 * S + qt0 * 256) * 4), sp2=S * 2, ldo2=ldo * 2,
                   cs=float(np.float32(scale * 1.4426950408889634)), nloop=(nt - 2) // 2, kmax=(nt - 1) * 16384,
-                  vmax=(nt - 1) * 128)
+                  vmax=(nt - 1) * 128, nblk=nblk, qt0=qt0, hh0=hh0, b0=b0, nq=nq, nh=H, kstep=S * 256, ostep=ostep,
+                  obs=S * ldo * 2, ob=("ptr", "O", 64), sq=stride % nq, dbh=stride // nq, qstride=stride * 65536,
+                  lstride=stride * 1024)
     if not with_lse:
-        inputs["l"] = 0
         inputs = {**{k_: v_ for k_, v_ in inputs.items() if k_ != "l"}, "l_lo": 0, "l_hi": 0}
     m = asm_emu.Machine(G.generate(), inputs, dict(Q=Q, K=K, V=Vt, O=O, L=lse), mode=mode, order=order).run()
-    qf, kf, vf = (_f32(x).astype(np.float64) for x in (Q, K, _bf16(v)))
-    s = qf[qt * 256:qt * 256 + 256] @ kf.T * scale
-    mx = s.max(1, keepdims=True)
-    p = np.exp(s - mx)
-    ref = p @ vf / p.sum(1, keepdims=True)
-    got = _f32(O[qt * 256:qt * 256 + 256, 32:160]).astype(np.float64)
-    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-    lse_err = np.abs(lse[qt * 256:qt * 256 + 256] - (mx[:, 0] + np.log(p.sum(1)))).max()
-    other = np.delete(O, np.s_[qt * 256:qt * 256 + 256], axis=0)
-    assert not other.any() and not O[:, :32].any() and not O[:, 160:].any(), "stores outside this workgroup's O block"
-    return rel, lse_err, lse, m
+    rels, lerrs = [], []
+    touched = np.zeros_like(O, dtype=bool)
+    for blk in range(first, first + nblk * stride, stride):
+        bh, qb = blk // nq, blk % nq
+        b, hh = bh // H, bh % H
+        qf, kf, vf = (_f32(x[bh]).astype(np.float64) for x in (Q, K, _bf16(v)))
+        s = qf[qb * 256:qb * 256 + 256] @ kf.T * scale
+        mx = s.max(1, keepdims=True)
+        p = np.exp(s - mx)
+        ref = p @ vf / p.sum(1, keepdims=True)
+        rows, cols = slice(qb * 256, qb * 256 + 256), slice(32 + hh * 128, 160 + hh * 128)
+        got = _f32(O[b, rows, cols]).astype(np.float64)
+        touched[b, rows, cols] = True
+        rels.append(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        if with_lse:
+            lerrs.append(np.abs(lse[bh, rows] - (mx[:, 0] + np.log(p.sum(1)))).max())
+            lse[bh, rows] = -7.0
+    assert not O[~touched].any(), "stores outside the workgroup's O blocks"
+    assert (lse == -7.0).all(), "lse stores outside the workgroup's blocks"
+    return max(rels), (max(lerrs) if lerrs else 0.0), lse, m
 
 
 def test_generated_file_is_current():
@@ -104,5 +122,22 @@ def test_emulated_rescale_fixup_runs_and_is_right(mode):
 
 
 def test_emulated_null_lse_pointer_stores_nothing():
-    rel, _, lse, _ = _emulate(256, "late", [0, 1, 2, 3], seed=3, with_lse=False)
+    rel, _, lse, _ = _emulate(256, "late", [0, 1, 2, 3], seed=3, with_lse=False, H=2, nblk=2)
     assert rel < 4e-3 and (lse == -7.0).all()
+
+
+@pytest.mark.parametrize("mode,order", [("late", [0, 1, 2, 3]), ("early", [3, 1, 2, 0])])
+def test_emulated_persistent_blocks_cross_heads_and_batches(mode, order):
+    """One workgroup walking five consecutive blocks of a [B = 2, H = 2, S = 512] problem, starting at the second q-tile of
+    (batch 0, head 0): q-tile wrap -> next head (K / V^T advance, O moves 128 columns), head wrap -> next batch; the next block's
+    tiles and Q fragments are fetched during the current block's last iteration behind a counted vmcnt."""
+    rel, lse_err, _, m = _emulate(512, mode, order, seed=5, B=2, H=2, first=1, nblk=5)
+    assert rel < 4e-3 and lse_err < 1e-5
+    assert m.mfma_count == 5 * 4 * 8 * 64
+
+
+def test_emulated_persistent_blocks_strided():
+    """Blocks 1, 4, 7, 10 of a [B = 2, H = 3, S = 512] problem (stride 3 > nq = 2: the head index advances by one or two per
+    step and wraps into the next batch), the order the XCD-interleaved launch walks."""
+    rel, lse_err, _, _ = _emulate(512, "late", [0, 1, 2, 3], seed=6, B=2, H=3, first=1, nblk=4, stride=3)
+    assert rel < 4e-3 and lse_err < 1e-5
