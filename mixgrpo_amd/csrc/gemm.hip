@@ -351,12 +351,18 @@ __global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restr
   }
 }
 
-__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N, float beta) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// Block = 64 columns x 4 lanes over the partial rows
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
+                                                            int N, float beta) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * N + n];
-  out[n] = beta * out[n] + s;
+  if (n < N)
+    for (int b = ky; b < nblk; b += 4) s += part[(long)b * N + n];
+  red[ky][cx] = s;
+  __syncthreads();
+  if (ky == 0 && n < N) out[n] = beta * out[n] + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 // ------------------------------------------------------------------------------------------ persistent variant
@@ -943,11 +949,11 @@ extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* cols
   if (fast) {
     dim3 grid(cdiv(N, 128), cdiv(ld_out, 128));
     transpose8_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
-    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 128), N, colsum_beta);
+    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 64), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 128), N, colsum_beta);
   } else {
     dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
     transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
-    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 256), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
+    if (colsum_out) colsum_finish_kernel<<<cdiv(N, 64), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
   }
   MGX_CHECK_LAUNCH();
   return MGX_OK;

@@ -183,20 +183,29 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const bf16_raw* __restr
   for (int c = threadIdx.x; c < 2 * D; c += 256) part[(long)blockIdx.x * 2 * D + c] = red[c];
 }
 
-// dshift[b, c] (+)= sum over the batch's blocks; gradients are bf16 [B, mod_ld] chunks of the modulation vector
-__global__ void ln_mod_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dshift,
-                                         bf16_raw* __restrict__ dscale, long mod_ld, int D, int blocks_per_batch) {
+// dshift[b, c] (+)= sum over the batch's blocks; gradients are bf16 [B, mod_ld] chunks of the modulation vector.
+// Block = 64 columns x 4 lanes over the blocks (a thread per column walking all partials alone is latency-bound).
+__global__ void __launch_bounds__(256) ln_mod_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dshift,
+                                                                bf16_raw* __restrict__ dscale, long mod_ld, int D,
+                                                                int blocks_per_batch) {
+  __shared__ float red[2][4][64];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+  const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < blocks_per_batch; ++k) {
-    const long blk = (long)b * blocks_per_batch + k;
-    s0 += part[(blk * 2 + 0) * D + c];
-    s1 += part[(blk * 2 + 1) * D + c];
+  if (c < D)
+    for (int k = ky; k < blocks_per_batch; k += 4) {
+      const long blk = (long)b * blocks_per_batch + k;
+      s0 += part[(blk * 2 + 0) * D + c];
+      s1 += part[(blk * 2 + 1) * D + c];
+    }
+  red[0][ky][cx] = s0;
+  red[1][ky][cx] = s1;
+  __syncthreads();
+  if (ky == 0 && c < D) {
+    dshift[(long)b * mod_ld + c] = f2bf((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]));
+    dscale[(long)b * mod_ld + c] = f2bf((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]));
   }
-  dshift[(long)b * mod_ld + c] = f2bf(s0);
-  dscale[(long)b * mod_ld + c] = f2bf(s1);
 }
 
 // ------------------------------------------------------------------------------------- QK norm + RoPE + split
@@ -358,7 +367,17 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
   }
 }
 
-// sum the per-block partials: one block per (which, 16-column slab); 256 threads = 16 columns x 16 row-lanes
+// sum the per-block partials in two stages (a single stage of 16 workgroups walking 12,096 partial rows took 174 us):
+// stage 1: workgroup g of G sums the rows g, g + G, ... of all 256 columns into row g of `mid`; stage 2: one block per
+// (which, 16-column slab), 256 threads = 16 columns x 16 row-lanes, sums the G rows of `mid` and accumulates into gq / gk.
+constexpr int QK_FIN_G = 128;
+__global__ void __launch_bounds__(256) qk_bwd_partial_kernel(const float* __restrict__ part, float* __restrict__ mid,
+                                                             long nblocks) {
+  float s = 0.f;
+  for (long k = blockIdx.x; k < nblocks; k += QK_FIN_G) s += part[k * 256 + threadIdx.x];
+  mid[(long)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) qk_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ gq,
                                                             float* __restrict__ gk, long nblocks) {
   __shared__ float red[16][17];
@@ -424,7 +443,7 @@ extern "C" int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
-  ln_mod_bwd_finish_kernel<<<dim3(cdiv(D, 256), batches), 256, 0, st>>>(ws, dshift, dscale, mod_ld, D, bpb);
+  ln_mod_bwd_finish_kernel<<<dim3(cdiv(D, 64), batches), 256, 0, st>>>(ws, dshift, dscale, mod_ld, D, bpb);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -445,7 +464,7 @@ extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* w
 }
 
 extern "C" long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch) {
-  return (long)cdiv(rows_per_batch, 64) * H * B * 2 * 128;
+  return ((long)cdiv(rows_per_batch, 64) * H * B + QK_FIN_G) * 2 * 128;    // per-block partials + the first stage's sums
 }
 
 extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
@@ -459,7 +478,10 @@ extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* w
   QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ld_dqkv, ws, H, S, Sp, rows_per_batch, s0};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
-  qk_bwd_finish_kernel<<<16, 256, 0, st>>>(ws, gwq, gwk, (long)grid.x * grid.y * grid.z);
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  float* mid = ws + nblocks * 256;
+  qk_bwd_partial_kernel<<<QK_FIN_G, 256, 0, st>>>(ws, mid, nblocks);
+  qk_bwd_finish_kernel<<<16, 256, 0, st>>>(mid, gwq, gwk, QK_FIN_G);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

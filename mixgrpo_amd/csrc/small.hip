@@ -159,14 +159,18 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const bf16_raw* __restric
   part[(long)blockIdx.y * D + c + 1] = a1;
 }
 
-__global__ void gate_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dgate, long gate_ld, int D,
-                                       int blocks_per_batch) {
+__global__ void __launch_bounds__(256) gate_bwd_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dgate,
+                                                              long gate_ld, int D, int blocks_per_batch) {
+  __shared__ float red[4][64];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+  const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int k = 0; k < blocks_per_batch; ++k) s += part[((long)b * blocks_per_batch + k) * D + c];
-  dgate[(long)b * gate_ld + c] = f2bf(s);
+  if (c < D)
+    for (int k = ky; k < blocks_per_batch; k += 4) s += part[((long)b * blocks_per_batch + k) * D + c];
+  red[ky][cx] = s;
+  __syncthreads();
+  if (ky == 0 && c < D) dgate[(long)b * gate_ld + c] = f2bf((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 }  // namespace
@@ -241,7 +245,7 @@ extern "C" int mgx_gate_bwd(const uint16_t* dout, long ldd, long d_bstride, cons
   hipStream_t st = (hipStream_t)stream;
   gate_bwd_kernel<<<dim3(cdiv(D, 512), batches * bpb), 256, 0, st>>>(dout, ldd, rows_per_batch, d_bstride, y, ldy, gate,
                                                                       gate_ld, dy, lddy, ws, rows_per_batch, D, bpb);
-  gate_bwd_finish_kernel<<<dim3(cdiv(D, 256), batches), 256, 0, st>>>(ws, dgate, gate_ld, D, bpb);
+  gate_bwd_finish_kernel<<<dim3(cdiv(D, 64), batches), 256, 0, st>>>(ws, dgate, gate_ld, D, bpb);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
