@@ -216,6 +216,13 @@ int mgx_skinny_linear(const uint16_t* x, long ldx, const uint16_t* W, long ldw, 
 /* dW[N,K] (fp32) += dout[Bn,N]^T x[Bn,K]; dbias[N] (fp32, optional) += column sums of dout */
 int mgx_skinny_wgrad(const uint16_t* dout, long ldd, const uint16_t* x, long ldx, float* dW, long ldw, float* dbias,
                      int Bn, int N, int K, void* stream);
+/* dx[Bn,K] (bf16; += when accumulate) = bf16(dout[Bn,N] W[N,K]), 1 <= Bn <= 8: the input gradient of the same skinny linears
+ * (autograd of diffusers' AdaLayerNormZero(.Single).linear / AdaLayerNormContinuous.linear, called from
+ * train_grpo_flux.py:600 `loss.backward()`), read straight from the row-major weight.  ws: fp32 scratch of
+ * mgx_skinny_dgrad_workspace(Bn, K) elements. */
+long mgx_skinny_dgrad_workspace(int Bn, int K);
+int mgx_skinny_dgrad(const uint16_t* dout, long ldd, const uint16_t* W, long ldw, uint16_t* dx, long lddx, float* ws,
+                     int Bn, int N, int K, int accumulate, void* stream);
 /* bf16 elementwise: op 0 y=silu(a) | 1 y=b*silu'(a) | 2 y=a+b | 3 y+=a */
 int mgx_ew_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, long n, int op, void* stream);
 /* diffusers Timesteps(256, flip_sin_to_cos=True, shift 0): out[b] = bf16([cos(t_b f) | sin(t_b f)]) */

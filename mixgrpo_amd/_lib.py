@@ -70,6 +70,8 @@ SIGNATURES = {
     "mgx_attn_bwd": (_I, [_P] * 13 + [_I] * 4 + [_L, _L, _F, _P]),
     "mgx_skinny_linear": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P]),
     "mgx_skinny_wgrad": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
+    "mgx_skinny_dgrad_workspace": (_L, [_I, _I]),
+    "mgx_skinny_dgrad": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P]),
     "mgx_ew_bf16": (_I, [_P, _P, _P, _L, _I, _P]),
     "mgx_sincos_embed": (_I, [_P, _P, _I, _P]),
     "mgx_cast_f32_bf16": (_I, [_P, _P, _L, _P]),

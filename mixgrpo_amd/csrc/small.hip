@@ -78,6 +78,78 @@ __global__ void __launch_bounds__(256) skinny_wgrad_kernel(const bf16_raw* __res
   }
 }
 
+// dx[b, k] (+)= bf16( sum_n dout[b, n] * W[n, k] ),  b < Bn <= 8: the input gradient of a skinny linear, straight from the
+// row-major weight (a 128x128-tile GEMM on a transposed copy of W ran 24 workgroups and read W twice).
+// Stage 1: workgroup (x, g) walks the weight rows n = g, g + G, ... of its 2048 columns (a thread = 8 columns, 16-byte loads);
+// dout of those rows sits in LDS as fp32 [row][8].  Stage 2 sums the G partials in a fixed order.
+constexpr int SD_G = 128;
+__global__ void __launch_bounds__(256) skinny_dgrad_kernel(const bf16_raw* __restrict__ dout, long ldd,
+                                                           const bf16_raw* __restrict__ W, long ldw, float* __restrict__ part,
+                                                           int Bn, int N, int K) {
+  extern __shared__ float dsh[];                           // [rows of this workgroup][8]
+  const int g = blockIdx.y;
+  const int nrows = (N - g + SD_G - 1) / SD_G;
+  for (int id = threadIdx.x; id < nrows * 8; id += 256) {
+    const int i = id >> 3, b = id & 7;
+    dsh[id] = b < Bn ? bf2f(dout[(long)b * ldd + g + (long)i * SD_G]) : 0.f;
+  }
+  __syncthreads();
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= K) return;
+  float acc[8][8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
+  const bf16_raw* wp = W + (long)g * ldw + c;
+  const long step = (long)SD_G * ldw;
+  int i = 0;
+  for (; i + 4 <= nrows; i += 4) {
+    uint4 u[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint4*>(wp + (i + q) * step);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float wv[8];
+      wv[0] = bf2f(u[q].x & 0xffff); wv[1] = bf2f(u[q].x >> 16); wv[2] = bf2f(u[q].y & 0xffff); wv[3] = bf2f(u[q].y >> 16);
+      wv[4] = bf2f(u[q].z & 0xffff); wv[5] = bf2f(u[q].z >> 16); wv[6] = bf2f(u[q].w & 0xffff); wv[7] = bf2f(u[q].w >> 16);
+      const float4 d0 = *reinterpret_cast<const float4*>(dsh + (i + q) * 8), d1 = *reinterpret_cast<const float4*>(dsh + (i + q) * 8 + 4);
+      const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b][e] += dv[b] * wv[e];
+    }
+  }
+  for (; i < nrows; ++i) {
+    const uint4 u = *reinterpret_cast<const uint4*>(wp + i * step);
+    float wv[8];
+    wv[0] = bf2f(u.x & 0xffff); wv[1] = bf2f(u.x >> 16); wv[2] = bf2f(u.y & 0xffff); wv[3] = bf2f(u.y >> 16);
+    wv[4] = bf2f(u.z & 0xffff); wv[5] = bf2f(u.z >> 16); wv[6] = bf2f(u.w & 0xffff); wv[7] = bf2f(u.w >> 16);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[b][e] += dsh[i * 8 + b] * wv[e];
+  }
+  for (int b = 0; b < Bn; ++b) {
+    float* pp = part + ((long)g * Bn + b) * K + c;
+    *reinterpret_cast<float4*>(pp) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
+  }
+}
+
+__global__ void __launch_bounds__(256) skinny_dgrad_finish_kernel(const float* __restrict__ part, bf16_raw* __restrict__ dx,
+                                                                  long lddx, int Bn, int K, int accumulate) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)Bn * K) return;
+  const int b = (int)(id / K), k = (int)(id - (long)b * K);
+  float s = 0.f;
+  for (int g = 0; g < SD_G; ++g) s += part[((long)g * Bn + b) * K + k];
+  bf16_raw* o = dx + (long)b * lddx + k;
+  const float r = rbf(s);                                  // the linear's backward output is a bf16 tensor ...
+  *o = f2bf(accumulate ? bf2f(*o) + r : r);                // ... added to the running bf16 sum
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 // op: 0 silu fwd (y = bf16(silu(a))) | 1 silu bwd (y = bf16(b * silu'(a))) | 2 add (y = bf16(a + b))
@@ -192,6 +264,22 @@ extern "C" int mgx_skinny_wgrad(const uint16_t* dout, long ldd, const uint16_t* 
   MGX_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "K must be a multiple of 4");
   int gx = cdiv(K, 1024);
   skinny_wgrad_kernel<<<dim3(gx, N), 256, 0, (hipStream_t)stream>>>(dout, ldd, x, ldx, dW, ldw, dbias, Bn, N, K);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" long mgx_skinny_dgrad_workspace(int Bn, int K) { return (long)SD_G * (Bn < 8 ? Bn : 8) * K; }
+
+extern "C" int mgx_skinny_dgrad(const uint16_t* dout, long ldd, const uint16_t* W, long ldw, uint16_t* dx, long lddx,
+                                float* ws, int Bn, int N, int K, int accumulate, void* stream) {
+  MGX_REQUIRE(dout && W && dx && ws, "null operand");
+  MGX_REQUIRE(Bn >= 1 && Bn <= 8, "skinny dgrad handles 1..8 rows per call");
+  MGX_REQUIRE(N >= SD_G && K % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)W % 16 == 0), "weight rows must be 16-byte addressable");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)cdiv(N, SD_G) * 8 * sizeof(float);
+  MGX_REQUIRE(lds <= 65536, "too many weight rows");
+  skinny_dgrad_kernel<<<dim3(cdiv(K, 2048), SD_G), 256, lds, st>>>(dout, ldd, W, ldw, ws, Bn, N, K);
+  skinny_dgrad_finish_kernel<<<cdiv((long)Bn * K, 256), 256, 0, st>>>(ws, dx, lddx, Bn, K, accumulate);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -209,10 +209,7 @@ def _skinny_bwd(model, tr, dmod, x, wname, bname, N, K, dx_acc):
     g = st.ensure_grad()
     ops.skinny_wgrad(dmod, x, st.view(g, wname), st.view(g, bname), N, K)
     if dx_acc is not None:
-        Bn = dmod.shape[0]
-        tmp = torch.empty(Bn, K, dtype=BF16, device=dmod.device)
-        _dgrad(model, tr, Rows.of(dmod), N, K, wname, Rows.of(tmp))
-        ops.ew(tmp, None, dx_acc, 3)
+        ops.skinny_dgrad(dmod, st.view(st.w16, wname), dx_acc, N, K)      # straight from the row-major weight
 
 
 def _backward(model, w, tr, sv, dout):

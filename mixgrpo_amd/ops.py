@@ -132,6 +132,16 @@ def skinny_wgrad(dout, x, dW, dbias, N, K):
                                      ptr(dbias), nb, N, K, stream()))
 
 
+def skinny_dgrad(dout, W, dx, N, K, accumulate=True):
+    """dx[Bn, K] (+)= bf16(dout[Bn, N] @ W[N, K]) from the row-major bf16 weight."""
+    Bn = dout.shape[0]
+    for b0 in range(0, Bn, 8):
+        nb = min(8, Bn - b0)
+        ws = scratch("skinny_dgrad", lib().mgx_skinny_dgrad_workspace(nb, K), F32, dout.device)
+        check(lib().mgx_skinny_dgrad(dout[b0:].data_ptr(), dout.stride(0), ptr(W), K, dx[b0:].data_ptr(), dx.stride(0),
+                                     ptr(ws), nb, N, K, 1 if accumulate else 0, stream()))
+
+
 def ew(a, b, y, op):
     check(lib().mgx_ew_bf16(ptr(a), ptr(b), ptr(y), a.numel(), op, stream()))
 
