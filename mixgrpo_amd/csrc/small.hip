@@ -9,22 +9,26 @@
 namespace {
 
 // out[b, n] = bf16( sum_k x[b,k] W[n,k] + bias[n] ),  b < Bn <= 16
+// Workgroup = 16 output features; its four waves split K (a wave walking all of K alone is latency-bound: 24 dependent
+// round trips for K = 3072, 2.9 TB/s on the 113 MB modulation weights) and wave 0 adds the four partial tiles.
 __global__ void __launch_bounds__(256) skinny_linear_kernel(const bf16_raw* __restrict__ x, long ldx,
                                                             const bf16_raw* __restrict__ W, long ldw,
                                                             const bf16_raw* __restrict__ bias,
                                                             bf16_raw* __restrict__ out, long ldo, int Bn, int N, int K) {
+  __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + w) * 16;
-  if (n0 >= N) return;
+  const int n0 = blockIdx.x * 16;
   const int fr = lane & 15, fq = lane >> 4;
   int nrow = n0 + fr;
   if (nrow >= N) nrow = N - 1;
   int brow = fr < Bn ? fr : Bn - 1;
+  const int kchunk = ((K / 32 + 3) / 4) * 32;              // K-steps of 32 per wave, rounded up
+  const int kbeg = min(w * kchunk, K), kend = min(kbeg + kchunk, K);
   const bf16_raw* wp = W + (long)nrow * ldw + fq * 8;
   const bf16_raw* xp = x + (long)brow * ldx + fq * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 128 <= K; k += 128) {
+  int k = kbeg;
+  for (; k + 128 <= kend; k += 128) {
     s16x8 a0 = *reinterpret_cast<const s16x8*>(wp + k), a1 = *reinterpret_cast<const s16x8*>(wp + k + 32);
     s16x8 a2 = *reinterpret_cast<const s16x8*>(wp + k + 64), a3 = *reinterpret_cast<const s16x8*>(wp + k + 96);
     s16x8 b0 = *reinterpret_cast<const s16x8*>(xp + k), b1 = *reinterpret_cast<const s16x8*>(xp + k + 32);
@@ -34,10 +38,18 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(const bf16_raw* __re
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b3, acc, 0, 0, 0);
   }
-  for (; k < K; k += 32) {
+  for (; k < kend; k += 32) {
     s16x8 a0 = *reinterpret_cast<const s16x8*>(wp + k);
     s16x8 b0 = *reinterpret_cast<const s16x8*>(xp + k);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+  }
+  if (w > 0) red[w - 1][lane] = acc;
+  __syncthreads();
+  if (w > 0) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const f32x4 o = red[i][lane];
+    acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
   }
   // D[i = n local][j = b]: lane holds b = fr, n = n0 + 4*fq + r
   if (fr < Bn) {
@@ -252,7 +264,7 @@ extern "C" int mgx_skinny_linear(const uint16_t* x, long ldx, const uint16_t* W,
   MGX_REQUIRE(x && W && out, "null operand");
   MGX_REQUIRE(Bn >= 1 && Bn <= 16, "skinny linear handles 1..16 rows");
   MGX_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "K must be a multiple of 32 with 16-byte aligned rows");
-  skinny_linear_kernel<<<cdiv(N, 64), 256, 0, (hipStream_t)stream>>>(x, ldx, W, ldw, bias, out, ldo, Bn, N, K);
+  skinny_linear_kernel<<<cdiv(N, 16), 256, 0, (hipStream_t)stream>>>(x, ldx, W, ldw, bias, out, ldo, Bn, N, K);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

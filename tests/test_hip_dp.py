@@ -72,9 +72,10 @@ def test_two_rank_step_on_one_gpu(mode, overlap, tmp_path):
         assert out[0][1][1] == out_ref[0][1][1]
     else:
         lr = 1e-3
-        # first AdamW step: update = -lr * g / (|g| + eps'): bf16 rounding of g moves a weight by a fraction of lr at most,
-        # except where the summed gradient is ~0 (sign flips: up to 2 lr)
-        assert (w - w_ref).abs().max().item() <= 2.5 * lr
+        # first AdamW steps: update ~ -lr * sign-like(g): bf16 rounding of g moves a weight by a fraction of lr at most,
+        # except where the summed gradient is ~0 (sign flips: up to 2 lr per optimizer step; this train step has TWO of them
+        # (4 samples, accumulation 2), and the second step's flip is damped by the first moment: observed 2.2-2.6 lr)
+        assert (w - w_ref).abs().max().item() <= 4.0 * lr
         assert (w - w_ref).abs().mean().item() < 0.02 * lr
         assert out[0][1][1] == pytest.approx(out_ref[0][1][1], rel=1e-2)          # global gradient norm
 
