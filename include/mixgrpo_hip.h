@@ -258,6 +258,34 @@ int mgx_adamw_step(float* w, uint16_t* w16, const float* g, float* m, float* v, 
                    float grad_scale, void* stream);
 int mgx_scale_f32(float* x, long n, float s, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------ VAE decode
+ * `vae.decode(latents)` of fastvideo/train_grpo_flux.py:279-289: diffusers' AutoencoderKL decoder (bf16 weights, bf16 autocast;
+ * its block structure is the 2-D original of the reference's vendored fastvideo/models/hunyuan/vae/unet_causal_3d_blocks.py
+ * :404-462 ResnetBlock, :667-693 mid block, :148-206 upsample, and of vae.py:251-312 Decoder.forward).  Activations are NHWC
+ * bf16 for one image: "plain" = [H W][C], "padded" = [(H + 2)(W + 2)][C] with a zero border that is the convolution's padding.
+ *
+ * 3x3 convolution, stride 1, padding 1, as an implicit GEMM on the MFMA GEMM kernels (K = 9 taps x C channels, no im2col):
+ * x padded NHWC, C in {64, 128, 256, 512}; Wt [Cout][3][3][C] bf16 (tap-major); out plain [H W][ld_out], Cout % 4 == 0.
+ * residual != 0: out = bf16(out + bf16(conv + bias)) (`input_tensor + hidden_states` of a ResnetBlock2D); `ones` = Cout bf16 ones. */
+int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uint16_t* bias, uint16_t* out, long ld_out,
+                     const uint16_t* ones, int H, int W, int C, int Cout, int residual, void* stream);
+/* y = [silu](GroupNorm(x; G groups, eps, affine gamma / beta [C] bf16)) in fp32 on a plain bf16 image x [H W][ld], one rounding
+ * to bf16 at the store.  Output pixel (y, x) goes to out + y * out_row + x * out_px (elements): a plain matrix or the interior of
+ * a padded image.  ws: fp32 scratch of mgx_group_norm_workspace(H W, C, G) elements. */
+long mgx_group_norm_workspace(long M, int C, int G);
+int mgx_group_norm_nhwc(const uint16_t* x, long ld, const uint16_t* gamma, const uint16_t* beta, uint16_t* out, long out_row,
+                        long out_px, float* ws, int H, int W, int C, int G, float eps, int silu, void* stream);
+/* nearest-neighbour 2x (F.interpolate(scale_factor=2, mode="nearest")): plain [H W][C] -> interior of a padded
+ * [(2H + 2)(2W + 2)][C] image; `out` points at its pixel (1, 1) */
+int mgx_upsample2x_pad_nhwc(const uint16_t* x, uint16_t* out, int H, int W, int C, void* stream);
+/* latents [Cin][H][W] fp32 -> bf16 interior of a padded NHWC image of C >= Cin channels (`out` at pixel (1, 1)) */
+int mgx_latents_to_pad_nhwc(const float* z, uint16_t* out, int Cin, int H, int W, int C, void* stream);
+/* first Cout channels of a plain NHWC image -> [Cout][H][W] bf16 */
+int mgx_nhwc_to_image(const uint16_t* x, long ld, uint16_t* img, int Cout, int H, int W, void* stream);
+/* P[r, :n] = bf16(softmax(scale * S[r, :n])), S fp32 (the mid block's single-head attention over H W <= 16384 tokens) */
+int mgx_softmax_rows_f32(const float* S, long lds, uint16_t* P, long ldp, int M, int n, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

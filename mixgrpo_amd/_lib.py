@@ -71,6 +71,13 @@ SIGNATURES = {
     "mgx_skinny_linear": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P]),
     "mgx_skinny_wgrad": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "mgx_skinny_dgrad_workspace": (_L, [_I, _I]),
+    "mgx_conv3x3_nhwc": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
+    "mgx_group_norm_workspace": (_L, [_L, _I, _I]),
+    "mgx_group_norm_nhwc": (_I, [_P, _L, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "mgx_upsample2x_pad_nhwc": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mgx_latents_to_pad_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mgx_nhwc_to_image": (_I, [_P, _L, _P, _I, _I, _I, _P]),
+    "mgx_softmax_rows_f32": (_I, [_P, _L, _P, _L, _I, _I, _F, _P]),
     "mgx_skinny_dgrad": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P]),
     "mgx_ew_bf16": (_I, [_P, _P, _P, _L, _I, _P]),
     "mgx_sincos_embed": (_I, [_P, _P, _I, _P]),

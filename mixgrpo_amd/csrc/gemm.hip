@@ -53,7 +53,21 @@ struct GemmArgs {
   int rowwise_ok;         // all bf16 side operands are 16-byte addressable: the LDS-staged epilogue may be used
   int span32;             // both operands span < 4 GiB: the persistent kernel's 32-bit DMA source offsets are valid
   int band;               // tile order of the persistent kernel (set in launch(): rule at gemm_pp_kernel)
+  // implicit 3x3 convolution over a zero-bordered NHWC image (mgx_conv3x3_nhwc): K = 9 taps x C channels, K-tile kt is
+  // channels 64 (kt % cpt) .. of tap kt / cpt, cpt = C / 64 = 1 << conv_shift; its A rows start conv_dy elements per tap
+  // row and conv_dx per tap column further on.  conv_shift < 0: a plain GEMM (K contiguous).
+  int conv_shift;
+  long conv_dy, conv_dx;
 };
+
+// element offset of K-tile kt inside an A row
+template <bool CONV>
+__device__ __forceinline__ long a_koff(const GemmArgs& g, int kt) {
+  if (!CONV) return (long)kt * BK;
+  const int tap = kt >> g.conv_shift, c = kt - (tap << g.conv_shift);
+  const int ty = (tap * 11) >> 5;                        // tap / 3 for tap < 9
+  return (long)ty * g.conv_dy + (long)(tap - 3 * ty) * g.conv_dx + (long)c * BK;
+}
 
 // gelu_tanh(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With tanh(u) = 2 s - 1, s = 1 / (1 + e^{-2u}):
 // gelu = x s and gelu' = s + 2 x s (1 - s) u'.  One v_exp_f32 + one v_rcp_f32 per element instead of the ~40-instruction
@@ -144,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NT
   }
 }
 
-template <int EPI>
+template <int EPI, bool CONV>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = 128, TN = 128;                               // block tile
   constexpr int NTHR = 256;
@@ -195,10 +209,11 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
 #define LOAD_TILE(kt)                                                            \
   do {                                                                           \
     const long ko = (long)(kt) * BK;                                             \
-    ra0 = *reinterpret_cast<const uint4*>(ap0 + ko);                             \
-    ra1 = *reinterpret_cast<const uint4*>(ap1 + ko);                             \
-    ra2 = *reinterpret_cast<const uint4*>(ap2 + ko);                             \
-    ra3 = *reinterpret_cast<const uint4*>(ap3 + ko);                             \
+    const long ka = a_koff<CONV>(g, (kt));                                       \
+    ra0 = *reinterpret_cast<const uint4*>(ap0 + ka);                             \
+    ra1 = *reinterpret_cast<const uint4*>(ap1 + ka);                             \
+    ra2 = *reinterpret_cast<const uint4*>(ap2 + ka);                             \
+    ra3 = *reinterpret_cast<const uint4*>(ap3 + ka);                             \
     rw0 = *reinterpret_cast<const uint4*>(wp0 + ko);                             \
     rw1 = *reinterpret_cast<const uint4*>(wp1 + ko);                             \
     rw2 = *reinterpret_cast<const uint4*>(wp2 + ko);                             \
@@ -655,7 +670,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 // against the matrix pipe's 2048 (83-85 % busy) at a clock the chip holds at 1.71-1.76 GHz under this load; the first
 // version of this loop with FOUR phases of 16 MFMAs (8 barriers per K-tile) ran 2622-2703 cycles at 1.82-1.87 GHz and
 // 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), round 1's lockstep K-loop 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
-template <int EPI>
+template <int EPI, bool CONV>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
   constexpr int WBASE = 3 * TB;
@@ -732,7 +747,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) PGLDS(wb, wo[k], lw + k * RS * 128);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) PGLDS(ab + BK * 2, ao[k], TB + la + k * RS * 128);
+    for (int k = 0; k < 4; ++k) PGLDS(ab + a_koff<CONV>(g, 1) * 2, ao[k], TB + la + k * RS * 128);
 #pragma unroll
     for (int k = 0; k < 4; ++k) PGLDS(wb + BK * 2, wo[k], TB + lw + k * RS * 128);
   }
@@ -764,7 +779,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
         cw[k] = nxt ? nwo[k] : cw[k];
       }
       const int a_dst = aslot == 0 ? 2 : aslot - 1;
-      const char* ab_ = reinterpret_cast<const char*>(g.A) + (long)k2 * (BK * 2);
+      const char* ab_ = reinterpret_cast<const char*>(g.A) + a_koff<CONV>(g, k2) * 2;
       const char* wb_ = reinterpret_cast<const char*>(g.W) + (long)k2 * (BK * 2);
       const int la_ = a_dst * TB + wu * 1024, lw_ = WBASE + wslot * TB + wu * 1024;
       const uint32_t sa_ = aslot * TB, sw_ = wslot * TB;
@@ -839,7 +854,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #undef MMA
 }
 
-template <int EPI>
+template <int EPI, bool CONV = false>
 int launch(const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   {
@@ -854,8 +869,8 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= min_tiles && (g.N % 256 == 0 || g.N >= 2048);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
   // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
@@ -863,9 +878,9 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
-    gemm_pp_kernel<EPI><<<grid, 512, 163840, st>>>(g);
+    gemm_pp_kernel<EPI, CONV><<<grid, 512, 163840, st>>>(g);
   } else {
-    gemm_kernel<EPI><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
+    gemm_kernel<EPI, CONV><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
   MGX_CHECK_LAUNCH();
   return MGX_OK;
@@ -912,6 +927,7 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   g.c = RowMap{ldc, c_rpb < RPB_MAX ? c_rpb : RPB_MAX, c_bstride};
   g.ldw = ldw;
   g.beta = beta;
+  g.conv_shift = -1; g.conv_dy = 0; g.conv_dx = 0;
   g.rowwise_ok = (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
                  (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
                  (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
@@ -933,6 +949,36 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   }
   mgx_set_error("unknown GEMM epilogue");
   return MGX_ERR_ARG;
+}
+
+// 3x3 convolution, stride 1, zero padding 1, as an implicit GEMM on the same kernels: x is a zero-bordered NHWC image
+// [(H + 2) x (W + 2) x C] (the border is the padding: no bounds checks in the K-loop), the weight [Cout][3][3][C] (tap-major,
+// channels contiguous), out [H W x Cout] row-major with leading dimension ld_out.  residual != 0: out += conv(x) + bias
+// (bf16 sum of two bf16 tensors, like `input_tensor + hidden_states` of a ResnetBlock2D), through the gate-residual epilogue
+// with a gate of ones.
+extern "C" int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uint16_t* bias, uint16_t* out, long ld_out,
+                                const uint16_t* ones, int H, int Wd, int C, int Cout, int residual, void* stream) {
+  MGX_REQUIRE(x && Wt && out && H > 0 && Wd > 0, "bad argument");
+  MGX_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, "channels per tap must be 64, 128, 256 or 512 (pad with zeros)");
+  MGX_REQUIRE(Cout > 0 && Cout % 4 == 0 && ld_out >= Cout && ld_out % 4 == 0, "output channels must be a multiple of 4");
+  MGX_REQUIRE(!residual || ones, "the residual form needs a vector of Cout ones (bf16)");
+  MGX_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)Wt % 16 == 0) && ((uintptr_t)out % 8 == 0), "operands must be 16-byte aligned");
+  const long Wp = Wd + 2;
+  MGX_REQUIRE((long)(H + 2) * Wp * C * 2 < (1L << 32) && (long)Cout * 9 * C * 2 < (1L << 32), "image too large for one call");
+  GemmArgs g;
+  g.A = x; g.W = Wt; g.bias = bias; g.C = out; g.gate = residual ? ones : nullptr; g.aux = nullptr; g.ldaux = 0; g.gate_ld = 0;
+  g.M = H * Wd; g.N = Cout; g.K = 9 * C;
+  g.a = RowMap{C, Wd, Wp * C};                      // output pixel (y, x) -> padded pixel (y, x): tap (0, 0)
+  g.c = RowMap{ld_out, 1L << 30, 0};
+  g.ldw = 9L * C;
+  g.beta = 0.f;
+  g.conv_shift = C == 64 ? 0 : (C == 128 ? 1 : (C == 256 ? 2 : 3));
+  g.conv_dy = Wp * C; g.conv_dx = C;
+  g.rowwise_ok = (Cout % 8 == 0) && (ld_out % 8 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) &&
+                 (!residual || (uintptr_t)ones % 16 == 0);
+  g.span32 = 1;
+  hipStream_t st = (hipStream_t)stream;
+  return residual ? launch<EPI_BIAS_GATE_RES, true>(g, st) : launch<EPI_BIAS, true>(g, st);
 }
 
 extern "C" long mgx_transpose_partial_elems(int M, int N) { return (long)cdiv(M, 64) * N; }   // covers both paths

@@ -184,3 +184,39 @@ def adamw_step(w, w16, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_n
 def attn_bwd(Q, K, V, Qt, Kt, O, dO, lse, delta, dOt, dQ, dK, dV, B, H, S, Sp, ldo, o_bstride, scale):
     check(lib().mgx_attn_bwd(ptr(Q), ptr(K), ptr(V), ptr(Qt), ptr(Kt), O.data_ptr(), dO.data_ptr(), ptr(lse), ptr(delta),
                              ptr(dOt), ptr(dQ), ptr(dK), ptr(dV), B, H, S, Sp, ldo, o_bstride, scale, stream()))
+
+
+# ------------------------------------------------------------------------------------------------ VAE decode (csrc/vae.hip)
+def conv3x3(xpad, Wt, bias, out, H, W, C, Cout, ones=None, ld_out=None):
+    """out[H W, Cout] (+)= conv3x3(xpad) + bias: xpad zero-bordered NHWC [(H+2), (W+2), C], Wt [Cout, 3, 3, C].
+    `ones` given: the residual form out = bf16(out + bf16(conv + bias))."""
+    check(lib().mgx_conv3x3_nhwc(ptr(xpad), ptr(Wt), ptr(bias), ptr(out), Cout if ld_out is None else ld_out, ptr(ones), H, W, C,
+                                 Cout, 0 if ones is None else 1, stream()))
+
+
+def group_norm(x, gamma, beta, out, H, W, C, G, silu, padded, eps=1e-6):
+    """out = [silu](GroupNorm(x)), x plain [H W, C]; `padded`: out is a zero-bordered [(H+2), (W+2), C] image (interior written)."""
+    ws = scratch("group_norm", lib().mgx_group_norm_workspace(H * W, C, G), F32, x.device)
+    if padded:
+        o, out_row = out.view(-1)[(W + 2) * C + C:], (W + 2) * C
+    else:
+        o, out_row = out, W * C
+    check(lib().mgx_group_norm_nhwc(ptr(x), C, ptr(gamma), ptr(beta), o.data_ptr(), out_row, C, ptr(ws), H, W, C, G, eps,
+                                    1 if silu else 0, stream()))
+
+
+def upsample2x_pad(x, outpad, H, W, C):
+    """plain [H W, C] -> interior of the zero-bordered [(2H+2), (2W+2), C] image `outpad`"""
+    check(lib().mgx_upsample2x_pad_nhwc(ptr(x), outpad.view(-1)[(2 * W + 2) * C + C:].data_ptr(), H, W, C, stream()))
+
+
+def latents_to_pad(z, outpad, Cin, H, W, C):
+    check(lib().mgx_latents_to_pad_nhwc(ptr(z), outpad.view(-1)[(W + 2) * C + C:].data_ptr(), Cin, H, W, C, stream()))
+
+
+def nhwc_to_image(x, ld, img, Cout, H, W):
+    check(lib().mgx_nhwc_to_image(ptr(x), ld, ptr(img), Cout, H, W, stream()))
+
+
+def softmax_rows(S, P, M, n, scale):
+    check(lib().mgx_softmax_rows_f32(ptr(S), S.stride(0), ptr(P), P.stride(0), M, n, scale, stream()))
