@@ -83,6 +83,7 @@ def main():
                          "chunk), whose GEMM tile counts sit closer to multiples of the 256 CUs than 6+6")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode side measurement (reported beside the metric)")
     ap.add_argument("--skip-dead-backward", action="store_true",
                     help="do not execute the backward passes of the G %% accum leftover samples, whose gradients the "
                          "reference computes and discards (identical outputs; NOT the default, NOT the headline number)")
@@ -363,10 +364,34 @@ def main():
                         "devices_visible": torch.cuda.device_count(),
                         "note": "measured on this run's ranks only; no 8-GPU number is extrapolated anywhere"}
         line["config"]["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MGX_")}
+        line["vae_decode"] = _vae_decode_side_measurement(dev, args, G) if not a.no_vae else None
         line["config"]["reward_seed"] = "1234 + 131 * step + rank (SURVEY 8d names 1234 + step; same distribution)"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _vae_decode_side_measurement(dev, args, G):
+    """Reported BESIDE the metric, never inside it: the step's reward stage is a synthetic function of the latents (the reward
+    networks' weights are not available offline), so the decode the reference runs before its reward models
+    (train_grpo_flux.py:279-289) is timed here on its own -- FLUX VAE configuration, random-init weights, one image of the
+    workload's resolution, after the timed region."""
+    try:
+        from mixgrpo_amd.vae import AutoencoderKL
+        vae = AutoencoderKL(device=dev).init_synthetic(seed=7)
+        vae.enable_tiling()
+        z = torch.randn(1, 16, args.h // 8, args.w // 8, device=dev)
+        vae.decode(z, return_dict=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vae.decode(z, return_dict=False)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        return {"ms_per_image": round(ms, 2), "ms_per_step_for_the_group": round(ms * G, 1), "resolution": f"{args.h}x{args.w}",
+                "note": "not part of `value`: decode + reward models sit behind reward_function(latents, captions)"}
+    except Exception as e:  # noqa: BLE001 - a side measurement must not cost the run its bench line
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
 def _lib_version():

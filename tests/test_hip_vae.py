@@ -165,3 +165,30 @@ def test_flux_vae_decode_1024_vs_oracle():
                "image_abs_mean": want.float().abs().mean().item()}, open("gpurun_out/r03_vae_decode.json", "w"), indent=1)
     assert got.shape == (1, 3, 1024, 1024)
     assert rel < 3e-2, rel
+
+
+def test_reward_adapter_runs_on_the_hip_vae():
+    """The decode + reward stage the trainer calls (mixgrpo_amd/reward_adapter.py = train_grpo_flux.py:279-316) with the HIP VAE
+    as its `vae`: packed rollout latents in, per-head rewards out, the decoded images equal to the oracle's `decode_latents`."""
+    from oracle import vae as OV
+    from mixgrpo_amd.reward_adapter import make_reward_function, decode_latents
+    kw = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, sample_size=64)     # 8x upsampling like FLUX's VAE
+    OV_, ocfg, P, m = _pair(kw, seed=8)
+    g = torch.Generator().manual_seed(3)
+    h = w = 64
+    lat = torch.randn(3, (h // 16) * (w // 16), 64, generator=g)
+    want = OV.decode_latents(P, ocfg, lat, h, w)
+    imgs = decode_latents(m, lat.cuda(), h, w)
+    assert imgs.shape == (3, 3, 64, 64)
+    assert _rel(imgs.float().cpu(), want.float()) < 2e-2
+    seen = {}
+
+    def brightness(images, prompts):
+        seen["n"] = (len(images), tuple(images[0].shape), list(prompts))
+        return [float(im.float().mean()) for im in images]
+
+    fn = make_reward_function(m, {"Brightness": brightness}, {"Brightness": 2.0}, h, w)
+    total, heads = fn(lat.cuda(), ["a", "b", "c"])
+    assert seen["n"] == (3, (3, 64, 64), ["a", "b", "c"])
+    assert len(total) == 3 and total[0] == pytest.approx(2.0 * heads["Brightness"][0])
+    assert heads["Brightness"][1] == pytest.approx(want[1].float().mean().item(), abs=2e-2)
