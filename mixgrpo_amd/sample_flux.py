@@ -5,8 +5,8 @@ The first `mix_sampling_steps` denoising steps run the GRPO-tuned transformer (`
 the rest the base transformer (:331-342); the schedule is the FLUX pipeline's dynamically shifted flow-matching
 schedule (`calculate_shift` mu from the image token count, :249-264, then diffusers'
 FlowMatchEulerDiscreteScheduler with `use_dynamic_shifting`), the update an Euler step in fp32 cast back to the latent
-dtype.  Text encoders, the VAE and PIL output are outside the hot path: the sampler takes cached prompt embeddings and
-returns packed latents (`unpack_latents` + VAE decode is the caller's, as in train_grpo_flux.py:279-289).
+dtype.  Text encoders are outside the hot path: the sampler takes cached prompt embeddings and returns packed latents, or -- given
+a VAE (`mixgrpo_amd.vae.AutoencoderKL`, the HIP decode) -- images, through the reference's tail (:387-393).
 
 `calculate_shift` and the sigma grid handed to the scheduler are held bit for bit to the reference's vendored helpers
 (fastvideo/models/flux_hf/pipeline_flux.py:73-84,87-145; tests/test_sampler_host.py, tests/golden/sampler_schedule.json).
@@ -45,9 +45,10 @@ def flow_match_sigmas(num_inference_steps, mu, sigmas=None):
 class DualFluxSampler:
     """`transformer`: base model, `transformer_new`: tuned model (both mixgrpo_amd.flux.FluxTransformer2DModel)."""
 
-    def __init__(self, transformer, transformer_new=None):
+    def __init__(self, transformer, transformer_new=None, vae=None):
         self.transformer = transformer
         self.transformer_new = transformer_new
+        self.vae = vae            # mixgrpo_amd.vae.AutoencoderKL (or any object with .config / .decode): needed for image outputs
 
     def load_new_model(self, model_path):
         """Reference :27-33: a second transformer with the tuned weights (a safetensors file in diffusers key names)."""
@@ -61,8 +62,12 @@ class DualFluxSampler:
     def __call__(self, prompt_embeds, pooled_prompt_embeds, height=1024, width=1024, num_inference_steps=28,
                  mix_sampling_steps=10, sigmas=None, guidance_scale=3.5, generator=None, latents=None,
                  true_cfg_scale=1.0, negative_prompt_embeds=None, negative_pooled_prompt_embeds=None,
-                 text_ids=None, max_sequence_length=512):
+                 text_ids=None, max_sequence_length=512, output_type="latent"):
+        """`output_type`: "latent" (packed latents, the default here) | "pt" ([B, 3, H, W] in [0, 1]) | "np" ([B, H, W, 3] float32)
+        | "pil" -- the reference's tail (:387-393): unpack, `/ scaling_factor + shift_factor`, `vae.decode`, postprocess."""
         dev = self.transformer.store.device
+        if output_type != "latent" and self.vae is None:
+            raise ValueError(f'output_type="{output_type}" needs a VAE: DualFluxSampler(..., vae=AutoencoderKL.from_pretrained(...))')
         if mix_sampling_steps > 0 and self.transformer_new is None:
             raise ValueError("mix_sampling_steps > 0 needs the tuned model: call load_new_model() first")
         B = prompt_embeds.shape[0]
@@ -97,4 +102,25 @@ class DualFluxSampler:
             # FlowMatchEulerDiscreteScheduler.step: fp32 Euler update, cast back to the model-output dtype
             dt = (sig[i + 1] - sig[i]).item()
             latents = (latents.to(torch.float32) + dt * noise_pred.to(torch.float32)).to(noise_pred.dtype)
-        return latents
+        if output_type == "latent":
+            return latents
+        return self.decode_latents(latents, height, width, output_type)
+
+    def decode_latents(self, latents, height, width, output_type="pt"):
+        """Reference :390-393 with diffusers' VaeImageProcessor.postprocess restated for its three plain outputs:
+        denormalise `(x / 2 + 0.5).clamp(0, 1)`; "np" = NHWC float32; "pil" = uint8 `(x * 255).round()` images."""
+        from .latents import unpack_latents
+        cfg = self.vae.config
+        z = unpack_latents(latents, height, width, 8)
+        z = (z / cfg.scaling_factor) + cfg.shift_factor
+        image = self.vae.decode(z, return_dict=False)[0]
+        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return image
+        arr = image.permute(0, 2, 3, 1).cpu().numpy()
+        if output_type == "np":
+            return arr
+        if output_type == "pil":
+            from PIL import Image
+            return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
+        raise ValueError(f"unknown output_type {output_type}")

@@ -59,6 +59,36 @@ def test_dual_sampler_vs_oracle(tmp_path):
     assert torch.equal(out2, out)
 
 
+def test_dual_sampler_image_outputs_through_the_hip_vae():
+    """The pipeline's tail (sample_flux.py:387-393): unpack, un-scale, `vae.decode`, postprocess -- on the HIP VAE, against the
+    oracle VAE applied to the sampler's own latents."""
+    from mixgrpo_amd.sample_flux import DualFluxSampler
+    from mixgrpo_amd.vae import AutoencoderKL, VaeConfig
+    from oracle import vae as OV
+    P_base, m_base = _pair(1)
+    vkw = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, sample_size=256)          # 8x, like the FLUX VAE
+    VP = OV.init_params(OV.VaeConfig(**vkw), seed=4)
+    vae = AutoencoderKL(VaeConfig(**vkw), device="cuda").load_state_dict({k: v.bfloat16() for k, v in VP.items()})
+    g = torch.Generator().manual_seed(0)
+    B, L, hw = 2, 24, 128
+    ehs = torch.randn(B, L, 64, generator=g).bfloat16()
+    pooled = torch.randn(B, 32, generator=g).bfloat16()
+    lat = torch.randn(B, 64, 64, generator=g).bfloat16()
+    s = DualFluxSampler(m_base, vae=vae)
+    kw = dict(height=hw, width=hw, num_inference_steps=3, mix_sampling_steps=0, latents=lat.cuda())
+    out_lat = s(ehs.cuda(), pooled.cuda(), **kw)
+    img = s(ehs.cuda(), pooled.cuda(), output_type="pt", **kw)
+    assert img.shape == (B, 3, hw, hw) and img.dtype == torch.float32 and 0.0 <= img.min().item() and img.max().item() <= 1.0
+    want = (OV.decode_latents(VP, OV.VaeConfig(**vkw), out_lat.float().cpu(), hw, hw).float() / 2 + 0.5).clamp(0, 1)
+    assert (img.cpu() - want).abs().mean().item() < 5e-3
+    arr = s(ehs.cuda(), pooled.cuda(), output_type="np", **kw)
+    assert arr.shape == (B, hw, hw, 3) and arr.dtype.name == "float32"
+    pil = s(ehs.cuda(), pooled.cuda(), output_type="pil", **kw)
+    assert len(pil) == B and pil[0].size == (hw, hw)
+    with pytest.raises(ValueError, match="needs a VAE"):
+        DualFluxSampler(m_base)(ehs.cuda(), pooled.cuda(), output_type="pt", **kw)
+
+
 def test_checkpoint_and_resume_roundtrip(tmp_path):
     from mixgrpo_amd.checkpoint import load_resume_state, save_checkpoint, save_resume_state
     from mixgrpo_amd.flux import FluxTransformer2DModel
