@@ -192,3 +192,34 @@ def test_reward_adapter_runs_on_the_hip_vae():
     assert seen["n"] == (3, (3, 64, 64), ["a", "b", "c"])
     assert len(total) == 3 and total[0] == pytest.approx(2.0 * heads["Brightness"][0])
     assert heads["Brightness"][1] == pytest.approx(want[1].float().mean().item(), abs=2e-2)
+
+
+def test_from_pretrained_reads_the_diffusers_layout(tmp_path):
+    """`AutoencoderKL.from_pretrained(path, subfolder="vae", torch_dtype=torch.bfloat16)` as the reference calls it
+    (train_grpo_flux.py:697-701): config.json + diffusion_pytorch_model.safetensors with diffusers key names; encoder / quant-conv
+    tensors and unknown config entries are ignored, a missing decoder tensor is an error."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from oracle import vae as OV
+    from mixgrpo_amd.vae import AutoencoderKL
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)
+    OV_, ocfg, P, m = _pair(kw, seed=2)
+    d = tmp_path / "model" / "vae"
+    os.makedirs(d)
+    json.dump({"_class_name": "AutoencoderKL", "block_out_channels": [64, 128], "layers_per_block": 1, "sample_size": 32,
+               "latent_channels": 16, "out_channels": 3, "norm_num_groups": 32, "scaling_factor": 0.3611, "shift_factor": 0.1159,
+               "use_quant_conv": False, "force_upcast": True, "act_fn": "silu", "mid_block_add_attention": True},
+              open(d / "config.json", "w"))
+    sd = {k: v.to(BF16).contiguous() for k, v in P.items()}
+    sd["encoder.conv_in.weight"] = torch.zeros(64, 3, 3, 3, dtype=BF16)
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    m2 = AutoencoderKL.from_pretrained(str(tmp_path / "model"), subfolder="vae", torch_dtype=BF16)
+    assert m2.config.block_out_channels == (64, 128) and m2.tile_latent_min_size == 16
+    z = torch.randn(1, 16, 12, 12, generator=torch.Generator().manual_seed(1)).cuda()
+    assert torch.equal(m2.decode(z, return_dict=False)[0], m.decode(z, return_dict=False)[0])
+    assert m2.decode(z)["sample"].shape == (1, 3, 24, 24)
+    del sd["decoder.conv_out.bias"]
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(KeyError, match="decoder tensors"):
+        AutoencoderKL.from_pretrained(str(tmp_path / "model"), subfolder="vae")
