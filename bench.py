@@ -377,6 +377,9 @@ def _vae_decode_side_measurement(dev, args, G):
     (train_grpo_flux.py:279-289) is timed here on its own -- FLUX VAE configuration, random-init weights, one image of the
     workload's resolution, after the timed region."""
     try:
+        free_gib = torch.cuda.mem_get_info()[0] / 2 ** 30
+        if free_gib < 8.0:           # scores + probabilities of the mid-block attention + activations: ~4 GiB at 1024^2
+            return {"skipped": f"only {free_gib:.1f} GiB of device memory free after the timed region"}
         from mixgrpo_amd.vae import AutoencoderKL
         vae = AutoencoderKL(device=dev).init_synthetic(seed=7)
         vae.enable_tiling()
