@@ -468,6 +468,10 @@ class Machine:
         self.wr(w, o[0], ((self.src(w, o[1]).astype(np.uint64) << (self.src(w, o[2]) & 31).astype(np.uint64)) +
                           self.src(w, o[3])).astype(U32))
 
+    def i_v_lshl_or_b32(self, w, ins, o):
+        self.wr(w, o[0], ((self.src(w, o[1]).astype(np.uint64) << (self.src(w, o[2]) & 31).astype(np.uint64)).astype(U32) |
+                          self.src(w, o[3])))
+
     def i_v_add_u32(self, w, ins, o):
         self.wr(w, o[0], (self.src(w, o[1]).astype(np.uint64) + self.src(w, o[2])).astype(U32))
 
