@@ -37,6 +37,8 @@ def test_bench_one_gpu_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert j["lib_version"] >= 100                              # a release build of the library (diagnostic builds: < 0)
     assert j["config"]["rollout_solver_steps"] == 8 and j["mfma_frac_train_step_executed"] <= j["mfma_frac_train_step"]
+    vd = j["vae_decode"]                                        # reported beside the metric, never inside it
+    assert vd["ms_per_image"] > 0 and "not part of `value`" in vd["note"]
 
 
 def test_bench_two_ranks_on_one_gpu():
