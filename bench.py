@@ -336,6 +336,7 @@ def main():
                            "grad_accum": args.gradient_accumulation_steps, "global_batch": world * G,
                            "seq_len": n_img + L, "parallelism": f"dp{world}", "train_microbatch": a.train_microbatch,
                            "train_ff_blocks_kept": (model.ff_blocks_kept() if hasattr(model, "ff_blocks_kept") else 0),
+                           "train_qkv_blocks_kept": (model.qkv_blocks_kept() if hasattr(model, "qkv_blocks_kept") else 0),
                            "skip_dead_backward": bool(a.skip_dead_backward),
                            "algorithmic_pflop_per_image": round(flop_img / 1e15, 3),
                            "executed_pflop_per_image": round(flop_img_executed / 1e15, 3)},

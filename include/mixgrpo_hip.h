@@ -149,6 +149,16 @@ enum { MGX_EPI_BIAS = 0, MGX_EPI_BIAS_GELU = 1, MGX_EPI_BIAS_GATE_RES = 2, MGX_E
 int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
                   uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                   long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream);
+/* The same GEMM with a caller-owned fp32 workspace of mgx_gemm_sk_workspace_elems() floats (one per stream in use): the
+ * persistent kernel may then share the tiles of its last, partial round out along K ("stream-K tail": partial sums through
+ * the workspace, added in K order by a second launch -- deterministic, and a given shape is always split the same way).
+ * Results can differ from mgx_gemm_bf16's in the last bit of the fp32 sum.  sk_workspace == NULL: identical to mgx_gemm_bf16.
+ * Replaces the same torch/cuBLAS nn.Linear launches (fastvideo/utils/sampling_utils.py:68-82, train_grpo_flux.py:134-144,600). */
+long mgx_gemm_sk_workspace_elems(void);
+int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
+                     uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                     long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
+                     long sk_workspace_elems, void* stream);
 
 /* out[N, ld_out] = in[M, N]^T (bf16; columns M..ld_out-1 are zero-filled) and, optionally, fp32 column sums
  * colsum_out[n] = beta*colsum_out[n] + sum_m in[m, n] (bias gradients) via a deterministic two-stage reduction;

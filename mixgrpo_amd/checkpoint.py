@@ -28,15 +28,20 @@ def save_checkpoint(transformer, rank, output_dir, step, epoch):
     return save_dir
 
 
-def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, global_step=0, rank=0):
-    """Writes `optimizer.safetensors` (m, v: flat fp32 in the parameter store's order) and `trainer_state.json`."""
+def save_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None, global_step=0, rank=0, epoch=0,
+                      steps_done=None):
+    """Writes `optimizer.safetensors` (m, v: flat fp32 in the parameter store's order) and `trainer_state.json`.
+    `global_step`: train steps finished inside the current epoch (the reference's inner loop position, `step - 1`);
+    `epoch`: the outer loop's epoch (the `-{epoch}` of the checkpoint's directory name); `steps_done`: train steps finished
+    over all epochs = prompt batches consumed = the reference's `global_step` counter (default: `global_step`, epoch 0)."""
     if rank > 0:
         return
     from safetensors.torch import save_file
     os.makedirs(save_dir, exist_ok=True)
     sd = optimizer.state_dict()
-    state = {"global_step": int(global_step), "optimizer_step": int(sd["step"]), "lr": float(sd["lr"]),
-             "base_lr": float(optimizer.base_lr)}
+    state = {"global_step": int(global_step), "epoch": int(epoch),
+             "steps_done": int(global_step if steps_done is None else steps_done),
+             "optimizer_step": int(sd["step"]), "lr": float(sd["lr"]), "base_lr": float(optimizer.base_lr)}
     if lr_scheduler is not None:
         state["lr_scheduler"] = {"n": int(lr_scheduler.n), "warmup": int(lr_scheduler.warmup),
                                  "base": [float(b) for b in lr_scheduler.base]}
@@ -103,9 +108,17 @@ def _json_scalar(x):
     raise TypeError(f"{type(x).__name__} is not JSON serialisable")
 
 
+def load_resume_position(save_dir):
+    """(epoch, steps finished inside that epoch, steps finished over all epochs) of a resume state; states written before
+    the epoch was recorded read as epoch 0."""
+    with open(os.path.join(save_dir, "trainer_state.json")) as f:
+        state = json.load(f)
+    return int(state.get("epoch", 0)), int(state["global_step"]), int(state.get("steps_done", state["global_step"]))
+
+
 def load_resume_state(save_dir, optimizer, lr_scheduler=None, grpo_states=None):
     """Restores what `save_resume_state` wrote (weights are loaded separately with `from_pretrained` /
-    `load_state_dict`).  Returns the global step to continue from."""
+    `load_state_dict`).  Returns the number of steps finished inside the saved epoch (`load_resume_position` has the epoch)."""
     from safetensors.torch import load_file
     with open(os.path.join(save_dir, "trainer_state.json")) as f:
         state = json.load(f)

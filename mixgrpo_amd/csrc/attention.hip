@@ -404,14 +404,21 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   static const int ovl = getenv("MGX_ATTN_OVL") ? atoi(getenv("MGX_ATTN_OVL")) : 1;
   const char* w64e = getenv("MGX_ATTN_W64");   // read per call: tests switch kernels inside one process
   const int w64 = w64e ? atoi(w64e) : 1;
-  if (w64 && S % 256 == 0 && Sp == S && (long)S * ldo * 2 < (1L << 31) && o_bstride * 2 < (1L << 31) && (long)S * 256 < (1L << 31)) {
+  // The persistent walk advances (q-tile, head, batch) by a fixed stride and carries ONCE per step (gen/attn_fwd64.py,
+  // block_advance_stores: head -= H, batch += 1), so a step must move the head index by less than H: stride / nq < H.
+  // (FLUX: H = 24, nq >= 3, stride 32.)  Shapes outside that -- S = 256 with many batches, few heads -- take attn_fwd_kernel.
+  const long nblk64 = (long)(S / 256) * H * B;
+  const int grid64 = nblk64 >= 256 ? 256 : (int)nblk64;
+  const int stride64 = (grid64 & 7) == 0 ? grid64 >> 3 : grid64;
+  const bool walk_ok = S >= 256 && stride64 / (S / 256) < H;
+  if (w64 && walk_ok && S % 256 == 0 && Sp == S && (long)S * ldo * 2 < (1L << 31) && o_bstride * 2 < (1L << 31) &&
+      (long)S * 256 < (1L << 31)) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       attr = true;
     }
-    const long nblk = (long)(S / 256) * H * B;
-    attn_fwd64_kernel<<<nblk >= 256 ? 256 : (int)nblk, 256, 65536, st>>>(g);
+    attn_fwd64_kernel<<<grid64, 256, 65536, st>>>(g);
     MGX_CHECK_LAUNCH();
     return MGX_OK;
   }

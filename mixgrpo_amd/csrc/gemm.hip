@@ -16,6 +16,7 @@
 #include "../../include/mixgrpo_hip.h"
 #include "common.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -58,6 +59,10 @@ struct GemmArgs {
   // row and conv_dx per tap column further on.  conv_shift < 0: a plain GEMM (K contiguous).
   int conv_shift;
   long conv_dy, conv_dx;
+  // stream-K tail of the persistent kernel (described at gemm_pp_kernel): sk_ws = fp32 workspace for partial tiles (null: off),
+  // sk_maxchunk = split an XCD's last, partial round only if no workgroup then gets more than this many of a tile's SK_DIV slices
+  float* sk_ws;
+  int sk_maxchunk;
 };
 
 // element offset of K-tile kt inside an A row
@@ -645,6 +650,95 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 }
 
 
+// ------------------------------------------------------------------------------------------ stream-K tail
+// A persistent launch takes ceil(tiles / 256) rounds, and the step is full of shapes whose last round is mostly idle: 2.25
+// rounds (the 3072 x 12288 weight gradients), 0.56 (3072 x 3072), 0.75 (the text stream), 3.375 / 4.2 (N = 3072 at micro-batch
+// 4 / 5): 0.55 s of a 13.1 s GEMM family (profiles/r03_gemm_shapes.jsonl).  So the LAST, partial round of every XCD is
+// shared out along K: each of its R tiles is cut into SK_DIV slices of K-tiles, the R * SK_DIV slices are dealt to the XCD's
+// `nw` workgroups in contiguous runs (workgroup w: slices [w R SK_DIV / nw, (w + 1) R SK_DIV / nw) -- at most two tiles), a
+// run that is not a whole tile leaves its raw fp32 accumulators in the workspace (slot 2 blockIdx + 0 | 1), and
+// gemm_sk_fixup_kernel adds a tile's segments IN K ORDER and runs the ordinary epilogue: deterministic (no atomics, no
+// flags, no spinning), and a given shape is always split the same way, so the training forward and its recompute stay
+// bit-identical.  What a split buys is (1 - chunk / SK_DIV) of a tile's K-loop, what it costs is the workspace round trip and
+// the fix-up launch; launch() only allows it when the former is clearly larger (sk_maxchunk).
+constexpr int SK_DIV = 8;
+constexpr long SK_SLOT = 256L * 256;      // floats per workspace slot
+
+__host__ __device__ inline int sk_chunk(int R, int nw) { return (SK_DIV * R + nw - 1) / nw; }
+__host__ __device__ inline bool sk_on(const float* ws, int maxchunk, int R, int nw, int nkt) {
+  return ws != nullptr && R > 0 && nkt >= 4 * SK_DIV && sk_chunk(R, nw) <= maxchunk;
+}
+
+struct SkTail {
+  int nfull;               // whole tiles of this workgroup (rounds before the tail)
+  int nseg;                // tail units: 0, 1 or 2
+  int tile0, k00, k01, part0;
+  int tile1, k11;          // the second segment always starts at K-tile 0 and is always partial
+};
+
+__device__ __forceinline__ SkTail sk_tail(const GemmArgs& g, int xcnt, int nw, int w, int nkt) {
+  SkTail t;
+  t.nfull = xcnt / nw;
+  const int R = xcnt - t.nfull * nw, base = t.nfull * nw;
+  t.nseg = 0; t.tile0 = 0; t.k00 = 0; t.k01 = nkt; t.part0 = 0; t.tile1 = 0; t.k11 = nkt;
+  if (!sk_on(g.sk_ws, g.sk_maxchunk, R, nw, nkt)) {
+    if (w < R) { t.nseg = 1; t.tile0 = base + w; }
+    return t;
+  }
+  const int DR = SK_DIV * R, lo = w * DR / nw, hi = (w + 1) * DR / nw;
+  if (lo == hi) return t;
+  const int a = lo / SK_DIV, s0 = lo - a * SK_DIV, s1 = min(SK_DIV, hi - a * SK_DIV);
+  t.nseg = 1; t.tile0 = base + a;
+  t.k00 = s0 * nkt / SK_DIV; t.k01 = s1 * nkt / SK_DIV;
+  t.part0 = (s0 != 0 || s1 != SK_DIV) ? 1 : 0;
+  if (hi > (a + 1) * SK_DIV) {
+    t.nseg = 2; t.tile1 = base + a + 1;
+    t.k11 = (hi - (a + 1) * SK_DIV) * nkt / SK_DIV;
+  }
+  return t;
+}
+
+// One wave per (tail tile, wave slot of the main kernel): blockIdx.x = (r * 8 + xcd) * 8 + wid.  Mirrors gemm_pp_kernel's
+// tile walk and sk_tail()'s dealing; tiles that one workgroup computed whole were finished there.
+template <int EPI>
+__global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
+  const int lane = threadIdx.x, wid = blockIdx.x & 7, xcd = (blockIdx.x >> 3) & 7, r = blockIdx.x >> 6;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, nwg = tiles_m * tiles_n, nkt = g.K / BK;
+  const int q = nwg >> 3, rem = nwg & 7;
+  const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int xcnt = xcd < rem ? q + 1 : q;
+  const int nfull = xcnt / nw, R = xcnt - nfull * nw;
+  if (r >= R || !sk_on(g.sk_ws, g.sk_maxchunk, R, nw, nkt)) return;
+  const int DR = SK_DIV * R;
+  // owner(s) = the workgroup whose run holds slice s = ceil((s + 1) nw / DR) - 1
+  const int w_first = ((r * SK_DIV + 1) * nw + DR - 1) / DR - 1;
+  const int w_last = ((r * SK_DIV + SK_DIV) * nw + DR - 1) / DR - 1;
+  if (w_first == w_last) return;                  // computed whole by one workgroup
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int w = w_first; w <= w_last; ++w) {       // ascending w = ascending K
+    const int lo = w * DR / nw, hi = (w + 1) * DR / nw;
+    if (lo == hi) continue;
+    const int seg = (lo / SK_DIV == r) ? 0 : 1;
+    const float* wsp = g.sk_ws + ((long)((w * 8 + xcd) * 2 + seg) << 16) + ((wid * 32) * 64 + lane) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(wsp + (i * 8 + j) * 256);
+        acc[i][j] += p;
+      }
+  }
+  const int tl = xbeg + nfull * nw + r, band = g.band;
+  const int per_band = band * tiles_n, b0 = tl / per_band, rows_in_band = min(band, tiles_m - b0 * band);
+  const int in_band = tl - b0 * per_band;
+  const long m0 = (long)(b0 * band + in_band % rows_in_band) * 256, n0 = (long)(in_band / rows_in_band) * 256;
+  persist_epilogue<EPI>(g, acc, wid, lane, m0, n0);
+}
+
 // ------------------------------------------------------------------------------------------ persistent ping-pong kernel
 // 256 workgroups (one per CU) x 8 waves walk 256x256x64 tiles.  Staging: all 160 KiB of LDS as THREE 32 KiB stages for A and
 // TWO for W, filled by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled through the per-lane SOURCE address) two K-tiles ahead;
@@ -685,9 +779,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd_wg = gridDim.x >> 3;
   const int q = nwg >> 3, rem = nwg & 7;
   const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  const int xend = xbeg + (xcd < rem ? q + 1 : q);
-  int t_lin = xbeg + lane_in_xcd;
-  if (t_lin >= xend) return;
+  const int xcnt = xcd < rem ? q + 1 : q;
+  // ---- the workgroup's list of work units: `nfull` whole tiles (xbeg + lane_in_xcd + i * per_xcd_wg), then -- stream-K tail --
+  // up to two SEGMENTS (tile, K-tile range) of the XCD's last, partial round (SkTail)
+  const SkTail sk = sk_tail(g, xcnt, per_xcd_wg, lane_in_xcd, nkt);
+  const int nunits = sk.nfull + sk.nseg;
+  if (nunits == 0) return;
 
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const bool late = wu >= 4;
@@ -736,18 +833,29 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #define PGLDS_K PGLDS
 #define LDA_K LDA
 #define LDW_K LDW
-  TILE_COORDS(t_lin, m0, n0);
+  // unit i of this workgroup -> (tile index inside the XCD's range, K-tile range, partial?)
+#define UNIT(i, T_, K0_, K1_, P_)                                                        \
+  do {                                                                                     \
+    const int s_ = (i) - sk.nfull;                                                         \
+    T_ = s_ < 0 ? lane_in_xcd + (i) * per_xcd_wg : (s_ == 0 ? sk.tile0 : sk.tile1);       \
+    K0_ = s_ < 0 ? 0 : (s_ == 0 ? sk.k00 : 0);                                             \
+    K1_ = s_ < 0 ? nkt : (s_ == 0 ? sk.k01 : sk.k11);                                      \
+    P_ = s_ < 0 ? 0 : (s_ == 0 ? sk.part0 : 1);                                            \
+  } while (0)
+  int ui = 0, u_tile, kbeg, kend, partial;
+  UNIT(0, u_tile, kbeg, kend, partial);
+  TILE_COORDS(xbeg + u_tile, m0, n0);
   TILE_OFFS(m0, n0, ao, wo);
-  {  // prologue: A K-tiles 0, 1 -> A slots 0, 1; W K-tiles 0, 1 -> W slots 0, 1
+  {  // prologue: A K-tiles kbeg, kbeg + 1 -> A slots 0, 1; W likewise -> W slots 0, 1
     const char* ab = reinterpret_cast<const char*>(g.A);
-    const char* wb = reinterpret_cast<const char*>(g.W);
+    const char* wb = reinterpret_cast<const char*>(g.W) + (long)kbeg * (BK * 2);
     const int la = wu * 1024, lw = WBASE + wu * 1024;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) PGLDS(ab, ao[k], la + k * RS * 128);
+    for (int k = 0; k < 4; ++k) PGLDS(ab + a_koff<CONV>(g, kbeg) * 2, ao[k], la + k * RS * 128);
 #pragma unroll
     for (int k = 0; k < 4; ++k) PGLDS(wb, wo[k], lw + k * RS * 128);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) PGLDS(ab + a_koff<CONV>(g, 1) * 2, ao[k], TB + la + k * RS * 128);
+    for (int k = 0; k < 4; ++k) PGLDS(ab + a_koff<CONV>(g, kbeg + 1) * 2, ao[k], TB + la + k * RS * 128);
 #pragma unroll
     for (int k = 0; k < 4; ++k) PGLDS(wb + BK * 2, wo[k], TB + lw + k * RS * 128);
   }
@@ -756,12 +864,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   if (late) __builtin_amdgcn_s_barrier();          // the late half runs one barrier behind from here on
   int aslot = 0, wslot = 0;
   while (true) {
-    const int t_next = t_lin + per_xcd_wg;
-    const bool has_next = t_next < xend;
+    const bool has_next = ui + 1 < nunits;
     long nm0 = 0, nn0 = 0;
+    int n_tile = u_tile, nkbeg = kbeg, nkend = kend, npartial = partial;   // no next unit: the look-ahead re-reads this one
     uint32_t nao[4] = {ao[0], ao[1], ao[2], ao[3]}, nwo[4] = {wo[0], wo[1], wo[2], wo[3]};
     if (has_next) {
-      TILE_COORDS(t_next, nm0, nn0);
+      UNIT(ui + 1, n_tile, nkbeg, nkend, npartial);
+      TILE_COORDS(xbeg + n_tile, nm0, nn0);
       TILE_OFFS(nm0, nn0, nao, nwo);
     }
     uint32_t ca[4] = {ao[0], ao[1], ao[2], ao[3]}, cw[4] = {wo[0], wo[1], wo[2], wo[3]};
@@ -770,9 +879,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
     for (int i = 0; i < NTL; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nkt; ++kt) {
-      const bool nxt = kt + 2 >= nkt;
-      const int k2 = nxt ? kt + 2 - nkt : kt + 2;
+    const int klen = kend - kbeg;                   // >= 2 (sk_tail)
+    for (int kt = 0; kt < klen; ++kt) {
+      const bool nxt = kt + 2 >= klen;
+      const int k2 = nxt ? nkbeg + (kt + 2 - klen) : kbeg + kt + 2;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         ca[k] = nxt ? nao[k] : ca[k];
@@ -833,14 +943,26 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
     asm volatile("" : "+v"(el), "+v"(ew));
     // (measured on the four-phase version and dropped: both halves running their epilogues in the SAME barrier interval --
     //  one extra barrier per half and tile -- is neutral; `s_setprio` around the MFMA sections is worth 2 %)
-    persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
+    if (partial) {
+      // stream-K segment: the raw accumulators go to this workgroup's workspace slot in register order (every store
+      // instruction of a wave writes 1 KiB contiguous); gemm_sk_fixup_kernel sums a tile's segments and runs the epilogue
+      float* wsp = g.sk_ws + ((long)(blockIdx.x * 2 + (ui - sk.nfull)) << 16) + ((ew * 32) * 64 + el) * 4;
+#pragma unroll
+      for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(wsp + (i * MT + j) * 256) = acc[i][j];
+    } else {
+      persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
+    }
     if (!has_next) break;
-    t_lin = t_next;
+    ++ui;
+    u_tile = n_tile; kbeg = nkbeg; kend = nkend; partial = npartial;
     m0 = nm0; n0 = nn0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ao[k] = nao[k]; wo[k] = nwo[k]; }
   }
   if (!late) __builtin_amdgcn_s_barrier();         // matches the late half's last barrier
+#undef UNIT
 #undef TILE_COORDS
 #undef TILE_OFFS
 #undef PGLDS
@@ -877,8 +999,34 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
-    if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
+    // stream-K tail (caller gave a workspace): allowed when it shortens the launch.  A tile's K-loop takes T ~ K * 0.0247 us
+    // (2 * 256 * 256 * K FLOP at the 5.3 TFLOP/s a CU sustains in this kernel).  Unsplit, the last round takes T; split, the
+    // busiest workgroup runs chunk / SK_DIV of a K-loop -- but ~1.45 x slower per K-tile than in a whole round, because the
+    // workgroups of an XCD are then at different K offsets of different tiles and no longer share their A / W panels in L2
+    // (profiles/r04_gemm_sk_ab.log: chunk 2 of 8 returns 14 % on the 2.25-round weight gradients where the K-loop alone says
+    // 25 %; chunk >= 6 loses) -- plus ~40 us for the workspace round trip and the fix-up launch:
+    //     split  <=>  T * (1 - 1.45 * chunk / SK_DIV) > 40 us.
+    static const float sk_cost_us = getenv("MGX_GEMM_SK_COST_US") ? (float)atof(getenv("MGX_GEMM_SK_COST_US")) : 40.f;
+    static const float sk_slow = getenv("MGX_GEMM_SK_SLOWDOWN") ? (float)atof(getenv("MGX_GEMM_SK_SLOWDOWN")) : 1.45f;
+    static const int sk_off = getenv("MGX_GEMM_SK") ? atoi(getenv("MGX_GEMM_SK")) == 0 : 0;
+    int rmax = 0;
+    g.sk_maxchunk = 0;
+    if (g.sk_ws && !sk_off && !CONV && g.K / BK >= 4 * SK_DIV) {
+      const float tile_us = (float)g.K * 0.0247f;
+      const int mc = (int)floorf((float)SK_DIV * (1.f - sk_cost_us / tile_us) / sk_slow);
+      g.sk_maxchunk = mc < 0 ? 0 : (mc > SK_DIV - 1 ? SK_DIV - 1 : mc);
+      const int nw = grid / 8, q = (int)(tiles_big >> 3), rem = (int)(tiles_big & 7);
+      for (int x = 0; x < 8; ++x) {
+        const int cnt = x < rem ? q + 1 : q, R = cnt % nw;
+        if (sk_on(g.sk_ws, g.sk_maxchunk, R, nw, g.K / BK) && R > rmax) rmax = R;
+      }
+    }
+    if (rmax == 0) {
+      g.sk_ws = nullptr;
+      if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
+    }
     gemm_pp_kernel<EPI, CONV><<<grid, 512, 163840, st>>>(g);
+    if (rmax > 0) gemm_sk_fixup_kernel<EPI><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
   } else {
     gemm_kernel<EPI, CONV><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
@@ -907,10 +1055,15 @@ __global__ void __launch_bounds__(256) gelu_rows_kernel(const bf16_raw* __restri
 
 }  // namespace
 
-extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
-                             uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
-                             long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream) {
+extern "C" long mgx_gemm_sk_workspace_elems(void) { return 256L * 2 * SK_SLOT; }
+
+extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
+                                uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                                long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
+                                long sk_workspace_elems, void* stream) {
   MGX_REQUIRE(A && W && C, "null operand");
+  MGX_REQUIRE(!sk_workspace || (sk_workspace_elems >= mgx_gemm_sk_workspace_elems() && (uintptr_t)sk_workspace % 16 == 0),
+              "stream-K workspace too small (mgx_gemm_sk_workspace_elems) or misaligned");
   MGX_REQUIRE(M > 0 && N > 0 && K > 0, "empty GEMM");
   MGX_REQUIRE(K % BK == 0, "K must be a multiple of 64");
   MGX_REQUIRE(N % 4 == 0, "N must be a multiple of 4");
@@ -928,6 +1081,7 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   g.ldw = ldw;
   g.beta = beta;
   g.conv_shift = -1; g.conv_dy = 0; g.conv_dx = 0;
+  g.sk_ws = sk_workspace; g.sk_maxchunk = 0;
   g.rowwise_ok = (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
                  (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
                  (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
@@ -949,6 +1103,13 @@ extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_
   }
   mgx_set_error("unknown GEMM epilogue");
   return MGX_ERR_ARG;
+}
+
+extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
+                             uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
+                             long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream) {
+  return mgx_gemm_bf16_sk(A, W, bias, C, gate, aux, ldaux, M, N, K, lda, a_rpb, a_bstride, ldw, ldc, c_rpb, c_bstride, gate_ld,
+                          epilogue, beta, nullptr, 0, stream);
 }
 
 // 3x3 convolution, stride 1, zero padding 1, as an implicit GEMM on the same kernels: x is a zero-bordered NHWC image
@@ -974,6 +1135,7 @@ extern "C" int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uin
   g.beta = 0.f;
   g.conv_shift = C == 64 ? 0 : (C == 128 ? 1 : (C == 256 ? 2 : 3));
   g.conv_dy = Wp * C; g.conv_dx = C;
+  g.sk_ws = nullptr; g.sk_maxchunk = 0;
   g.rowwise_ok = (Cout % 8 == 0) && (ld_out % 8 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) &&
                  (!residual || (uintptr_t)ones % 16 == 0);
   g.span32 = 1;

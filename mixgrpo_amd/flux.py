@@ -315,11 +315,12 @@ class FluxTransformer2DModel(torch.nn.Module):
         return total.squeeze(0)
 
     def grow_ff_keep(self, reserve_gib=None):
-        """Spend the device memory that is still free (beyond a reserve) on kept FF pre-activations, so that the training
-        pass's recompute skips those blocks' d -> 4d GEMM (flux_backward.KEEP_FF = "auto").  Called by `train_one_step` at
-        the start of its second step, when the first has shown the step's real peak.  Returns the number of blocks kept."""
+        """Spend the device memory that is still free (beyond a reserve) on kept FF pre-activations and QKV outputs, so that
+        the training pass's recompute skips those blocks' d -> 4d / d -> 3d GEMMs (flux_backward.KEEP_FF / KEEP_QKV =
+        "auto").  Called by `train_one_step` at the start of its second step, when the first has shown the step's real peak.
+        Returns the number of blocks whose FF pre-activation is kept."""
         from . import flux_backward as FB
-        if FB.KEEP_FF != "auto" or not FB.KEEP_ACTS:
+        if not FB.KEEP_ACTS or (FB.KEEP_FF != "auto" and FB.KEEP_QKV != "auto"):
             return self.ff_blocks_kept()
         reserve = (FB.KEEP_FF_RESERVE_GIB if reserve_gib is None else reserve_gib) * 2.0 ** 30
         for base in self._work.values():
@@ -327,13 +328,14 @@ class FluxTransformer2DModel(torch.nn.Module):
             if tr is None or tr.keep is None:
                 continue
             free, _total = torch.cuda.mem_get_info(self.store.device)
-            n = int((free - reserve) // tr.ff_block_bytes())
-            if n > 0:
-                tr.grow_ff(tr.ff_kept() + n)
+            tr.grow_auto(int(free - reserve))
         return self.ff_blocks_kept()
 
     def ff_blocks_kept(self):
         return sum(b.train.ff_kept() for b in self._work.values() if b.train is not None and b.train.keep is not None)
+
+    def qkv_blocks_kept(self):
+        return sum(b.train.qkv_kept() for b in self._work.values() if b.train is not None and b.train.keep is not None)
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B, L, N):
@@ -443,10 +445,12 @@ class FluxTransformer2DModel(torch.nn.Module):
             Xs = self._stream_rows(w.X if x_in is None else x_in, w, name, d)
             M = B * rows
             nrm = (w.nrm if save is None else save["nrm1"])[row0[name]:row0[name] + M]
-            qkv = w.qkv[row0[name]:row0[name] + M]
+            qkv_kept = keep is not None and "qkv" in keep       # QKV output kept by the forward: no GEMM in the recompute
+            qkv = (keep["qkv"] if qkv_kept else w.qkv)[row0[name]:row0[name] + M]
             ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm, d)
-            ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
-                     self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv), 3 * d, d)
+            if not (replay and qkv_kept):
+                ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
+                         self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv), 3 * d, d)
             ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
                              w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
@@ -507,8 +511,11 @@ class FluxTransformer2DModel(torch.nn.Module):
         Xa = Rows(w.X if x_in is None else x_in, M, d, S, S * d)
         nrm = w.nrm if save is None else save["nrm1"]
         ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, nrm, d)
-        ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
-                 self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(w.qkv), 3 * d, d)
+        qkv_kept = keep is not None and "qkv" in keep           # as in `_double_block`
+        qkv = keep["qkv"] if qkv_kept else w.qkv
+        if not (replay and qkv_kept):
+            ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
+                     self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(qkv), 3 * d, d)
         cat2 = w.cat.view(M, 5 * d)
         # the pre-activation (when kept) goes to columns 3d..7d of the [M, 7d] gradient staging buffer's twin
         ff_kept = keep is not None and "hid_pre" in keep
@@ -518,7 +525,7 @@ class FluxTransformer2DModel(torch.nn.Module):
             ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
                      Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
                      aux=save["hid_pre"] if save is not None else (keep["hid_pre"] if ff_kept else None))
-        ops.qk_norm_rope(w.qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
+        ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
                          w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward

@@ -26,6 +26,11 @@ KEEP_ACTS = os.environ.get("MGX_KEEP_ACTS", "1") != "0"
 # beyond `KEEP_FF_RESERVE_GIB` (`FluxTransformer2DModel.grow_ff_keep`).  Values kept are the very values a recompute produces.
 KEEP_FF = os.environ.get("MGX_KEEP_FF_BLOCKS", "auto")
 KEEP_FF_RESERVE_GIB = float(os.environ.get("MGX_KEEP_FF_RESERVE_GIB", "12"))
+# Likewise the fused QKV projection's output ([M, 3d] bf16 per block: 0.085 GB per sample): the recompute pass then skips the
+# d -> 3d GEMM as well (1/4 of a block's linear FLOPs) and only re-runs the elementwise QK-RMSNorm + RoPE on the kept rows.
+# "auto": handed out together with the FF pre-activations, block by block (FF first), from the memory that is still free.
+# With both kept for every block the recompute pass runs NO GEMM at all (micro-batch 4 at FLUX.1-dev 1024^2 on 288 GB).
+KEEP_QKV = os.environ.get("MGX_KEEP_QKV_BLOCKS", "auto")
 
 
 def _pad64(n):
@@ -59,8 +64,11 @@ class _Train:
                     k.update(y_ff=e(M, d), x_mid=e(B, S, d))
                 self.keep.append(k)
             self._ff_shape, self._ff_device = (M, 4 * d), device
+            self._qkv_shape = (M, 3 * d)
             if KEEP_FF != "auto":
                 self.grow_ff(int(KEEP_FF))
+            if KEEP_QKV != "auto":
+                self.grow_qkv(int(KEEP_QKV))
         self.save = dict(nrm1=e(M, d), nrm2=e(M, d), y_attn=e(M, d), y_ff=e(M, d), hid_pre=e(M, 4 * d),
                          x_mid=e(B, S, d), V=e(B, H, S, hd), Qt=z(B, H, hd, Sp), Kt=z(B, H, hd, Sp))
         self.dX = e(B, S, d)
@@ -86,6 +94,12 @@ class _Train:
     def ff_kept(self):
         return sum(1 for k in (self.keep or []) if "hid_pre" in k)
 
+    def qkv_block_bytes(self):
+        return self._qkv_shape[0] * self._qkv_shape[1] * 2
+
+    def qkv_kept(self):
+        return sum(1 for k in (self.keep or []) if "qkv" in k)
+
     def grow_ff(self, n_total):
         """Keep the FF pre-activation of the first `n_total` blocks (allocates the missing buffers)."""
         if self.keep is None:
@@ -94,6 +108,32 @@ class _Train:
             if "hid_pre" not in k:
                 k["hid_pre"] = torch.empty(*self._ff_shape, dtype=BF16, device=self._ff_device)
         return self.ff_kept()
+
+    def grow_qkv(self, n_total):
+        """Keep the QKV projection's output of the first `n_total` blocks (allocates the missing buffers)."""
+        if self.keep is None:
+            return 0
+        for k in self.keep[:max(0, n_total)]:
+            if "qkv" not in k:
+                k["qkv"] = torch.empty(*self._qkv_shape, dtype=BF16, device=self._ff_device)
+        return self.qkv_kept()
+
+    def grow_auto(self, budget_bytes):
+        """Spend `budget_bytes` block by block, FF pre-activation before QKV output, on whatever is still recomputed and
+        set to "auto".  Returns the bytes left."""
+        if self.keep is None:
+            return budget_bytes
+        for i, k in enumerate(self.keep):
+            for name, auto, size, grow in (("hid_pre", KEEP_FF == "auto", self.ff_block_bytes(), self.grow_ff),
+                                           ("qkv", KEEP_QKV == "auto", self.qkv_block_bytes(), self.grow_qkv)):
+                if name in k or not auto:
+                    continue
+                if budget_bytes < size:
+                    return budget_bytes
+                k[name] = torch.empty(*(self._ff_shape if name == "hid_pre" else self._qkv_shape), dtype=BF16,
+                                      device=self._ff_device)
+                budget_bytes -= size
+        return budget_bytes
 
 
 class _TrainView:
@@ -109,7 +149,7 @@ class _TrainView:
         self.save = {k: (v[:M] if k in rows else v[:B]) for k, v in base.save.items()}
         self.keep = None
         if base.keep is not None:
-            self.keep = [{k: (v[:M] if k in ("y_attn", "y_ff", "hid_pre") else v[:B]) for k, v in kb.items()}
+            self.keep = [{k: (v[:M] if k in ("y_attn", "y_ff", "hid_pre", "qkv") else v[:B]) for k, v in kb.items()}
                          for kb in base.keep]
         self.dX, self.dO, self.dQ, self.dK, self.dV, self.dOt, self.delta = (
             t[:B] for t in (base.dX, base.dO, base.dQ, base.dK, base.dV, base.dOt, base.delta))
@@ -285,7 +325,8 @@ def _backward(model, w, tr, sv, dout):
         ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK,
                      tr.dV, B, H, S, Sp, 5 * d, S * 5 * d, scale)
         # qk norm / rope backward writes [dq|dk|dv] straight into columns 0..3d of the [M, 7d] staging matrix
-        ops.qk_norm_rope_bwd(w.qkv, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
+        qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
+        ops.qk_norm_rope_bwd(qkv_b, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
                              tr.dQ, tr.dK, tr.dV, dbig, store.view(g32, f"{p}.attn.norm_q.weight"),
                              store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0, ld_dqkv=7 * d)
         dbr = Rows.of(dbig)
@@ -347,7 +388,8 @@ def _backward(model, w, tr, sv, dout):
             sl = slice(r0, r0 + Ms)
             dXs = srows(tr.dX, name, d)
             dqkv = tr.dbig.view(-1)[:M * 3 * d].view(M, 3 * d)[sl]
-            ops.qk_norm_rope_bwd(w.qkv[sl], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
+            qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
+            ops.qk_norm_rope_bwd(qkv_b[sl], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
                                  sin, tr.dQ, tr.dK, tr.dV, dqkv, store.view(g32, f"{p}.attn.{nq}.weight"),
                                  store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0)
             nrm1 = save["nrm1"][sl]

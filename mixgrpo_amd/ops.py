@@ -1,5 +1,6 @@
 """Thin Python wrappers over the C-ABI MMDiT kernels (device tensors in, device tensors out, current stream).
 Only plumbing lives here: shape bookkeeping and pointer passing.  See include/mixgrpo_hip.h for semantics."""
+import os
 from dataclasses import dataclass
 
 import torch
@@ -45,9 +46,27 @@ GEMM_PROFILE = None
 
 
 def _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux):
-    check(lib().mgx_gemm_bf16(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), None if gate is None else gate.data_ptr(),
-                              None if aux is None else aux.data_ptr(), (N if ldaux is None else ldaux), A.M, N, K, A.ld, A.rpb,
-                              A.bstride, K if ldw is None else ldw, C.ld, C.rpb, C.bstride, gate_ld, epi, beta, stream()))
+    ws = _sk_workspace(C.t.device) if GEMM_STREAM_K else None
+    check(lib().mgx_gemm_bf16_sk(ptr(A.t), ptr(W), ptr(bias), ptr(C.t), None if gate is None else gate.data_ptr(),
+                                 None if aux is None else aux.data_ptr(), (N if ldaux is None else ldaux), A.M, N, K, A.ld,
+                                 A.rpb, A.bstride, K if ldw is None else ldw, C.ld, C.rpb, C.bstride, gate_ld, epi, beta,
+                                 None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream()))
+
+
+# Stream-K tail of the persistent GEMM (csrc/gemm.hip): on by default; MGX_GEMM_STREAM_K=0 calls the kernel without a
+# workspace (every tile computed whole: results independent of the batch size).
+GEMM_STREAM_K = os.environ.get("MGX_GEMM_STREAM_K", "1") != "0"
+_sk_ws = {}
+
+
+def _sk_workspace(device):
+    """The caller-owned fp32 workspace of mgx_gemm_bf16_sk: one per (device, stream) that launches GEMMs."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    w = _sk_ws.get(key)
+    if w is None:
+        w = torch.empty(lib().mgx_gemm_sk_workspace_elems(), dtype=F32, device=device)
+        _sk_ws[key] = w
+    return w
 
 
 _scratch = {}

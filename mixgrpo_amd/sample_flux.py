@@ -108,13 +108,14 @@ class DualFluxSampler:
 
     def decode_latents(self, latents, height, width, output_type="pt"):
         """Reference :390-393 with diffusers' VaeImageProcessor.postprocess restated for its three plain outputs:
-        denormalise `(x / 2 + 0.5).clamp(0, 1)`; "np" = NHWC float32; "pil" = uint8 `(x * 255).round()` images."""
+        denormalise `(x / 2 + 0.5).clamp(0, 1)` IN THE DECODER'S DTYPE (bf16), then `.float()`; "np" = NHWC float32;
+        "pil" = uint8 `(x * 255).round()` images.  Parity unpinned: diffusers is not importable here."""
         from .latents import unpack_latents
         cfg = self.vae.config
         z = unpack_latents(latents, height, width, 8)
         z = (z / cfg.scaling_factor) + cfg.shift_factor
         image = self.vae.decode(z, return_dict=False)[0]
-        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        image = (image / 2 + 0.5).clamp(0, 1).float()
         if output_type == "pt":
             return image
         arr = image.permute(0, 2, 3, 1).cpu().numpy()

@@ -528,8 +528,8 @@ def reward_weights_from_args(args):
 def main(args, reward_function=None, reward_weights=None):
     """The reference's main() (:627-892) on this engine: replica data parallelism instead of FSDP (the flags that configure
     FSDP / activation checkpointing / sequence parallelism are accepted and have no effect), a JSON log line per step instead of
-    wandb, and a `--resume_from_checkpoint` that actually resumes (weights, AdamW moments, LR position, SDE-window state, global
-    step and every rank's generator states)."""
+    wandb, and a `--resume_from_checkpoint` that actually resumes (weights, AdamW moments, LR position, SDE-window state, epoch,
+    position inside the epoch, global step, data position and every rank's generator states), from a checkpoint of any epoch."""
     import json
     import os
     import time
@@ -538,7 +538,8 @@ def main(args, reward_function=None, reward_weights=None):
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
 
-    from .checkpoint import load_resume_state, load_rng_state, save_checkpoint, save_resume_state, save_rng_state
+    from .checkpoint import (load_resume_position, load_resume_state, load_rng_state, save_checkpoint, save_resume_state,
+                             save_rng_state)
     from .flux import FluxTransformer2DModel
     from .grpo_states import GRPOTrainingStates
     from .latent_flux_rl_datasets import LatentDataset, latent_collate_function
@@ -595,31 +596,39 @@ def main(args, reward_function=None, reward_weights=None):
             prog_overlap_step=args.prog_overlap_step, max_iters_per_group=args.max_iters_per_group,
             min_iters_per_group=args.min_iters_per_group, roll_back=args.roll_back)
 
-    init_steps = 0
+    init_steps, start_epoch, steps_done = 0, 0, 0
     if args.resume_from_checkpoint:
         init_steps = load_resume_state(args.resume_from_checkpoint, optimizer, lr_scheduler, grpo_states)
-        for _ in range(init_steps):                     # the prompts the finished steps consumed (one batch per train step)
-            next(loader)
+        start_epoch, _, steps_done = load_resume_position(args.resume_from_checkpoint)
+        # the prompts the finished steps consumed (one batch per train step), drawn exactly as the uninterrupted run drew
+        # them: every finished epoch's `set_epoch` before its steps, so the dataloader reshuffles at the same positions
+        for e in range(start_epoch + 1):
+            sampler.set_epoch(e)
+            for _ in range(args.max_train_steps if e < start_epoch else init_steps):
+                next(loader)
         load_rng_state(args.resume_from_checkpoint, rk)  # last: nothing below draws from a generator before the next step does
-        main_print(f"--> resumed from {args.resume_from_checkpoint} at step {init_steps}")
+        main_print(f"--> resumed from {args.resume_from_checkpoint} at epoch {start_epoch}, step {init_steps} "
+                   f"({steps_done} train steps done)")
     main_print("***** Running training *****")
     main_print(f"  Num examples = {len(train_dataset)}  world size = {ws}  resume step = {init_steps}")
     main_print(f"  Gradient Accumulation steps = {args.gradient_accumulation_steps}  steps per epoch = {args.max_train_steps}")
 
     step_times = deque(maxlen=100)
     resumed, first_step = bool(args.resume_from_checkpoint), init_steps + 1      # (the resumed-from checkpoint is not rewritten)
-    global_step = init_steps - 1
+    global_step = steps_done - 1
     log_path = os.path.join(run_dir, "train_log.jsonl") if run_dir and rk <= 0 else None
     epochs = 1000000 if args.mgx_max_epochs is None else args.mgx_max_epochs
-    for epoch in range(epochs):
+    for epoch in range(start_epoch, epochs):
         sampler.set_epoch(epoch)
         for step in range(init_steps + 1, args.max_train_steps + 1):
             global_step += 1
             start_time = time.time()
-            if step % args.checkpointing_steps == 0 and run_dir is not None and not (resumed and step == first_step):
+            if step % args.checkpointing_steps == 0 and run_dir is not None and \
+                    not (resumed and step == first_step and epoch == start_epoch):
                 d = save_checkpoint(transformer, rk, run_dir, step, epoch)
                 # (what the NEXT step needs to continue: it is `step` itself that has not run yet)
-                save_resume_state(d, optimizer, lr_scheduler, grpo_states, global_step=step - 1, rank=rk)
+                save_resume_state(d, optimizer, lr_scheduler, grpo_states, global_step=step - 1, rank=rk, epoch=epoch,
+                                  steps_done=global_step)
                 if ws > 1:
                     dist.barrier()                      # the directory exists before the other ranks write into it
                 save_rng_state(d, rk)

@@ -137,8 +137,8 @@ class AutoencoderKL:
             t = self._buf[key] = torch.empty(M, C, dtype=dtype, device=self.device)
         return t
 
-    def _padded(self, H, W, C):
-        key = ("pad", H, W, C)
+    def _padded(self, H, W, C, tag="pad"):
+        key = (tag, H, W, C)
         t = self._buf.get(key)
         if t is None:                                           # zero border = the convolutions' padding; interiors only are written
             t = self._buf[key] = torch.zeros(H + 2, W + 2, C, dtype=BF16, device=self.device)
@@ -198,7 +198,10 @@ class AutoencoderKL:
         ch = list(reversed(c.block_out_channels))
         _, H, W = z.shape
         Cz = _pad_ch(c.latent_channels)
-        pad = self._padded(H, W, Cz)
+        # its own buffer: only the first `latent_channels` of its Cz channels are ever written, the rest must stay the zeros of
+        # the allocation (conv_in's weight is zero there, but 0 * inf = NaN) -- the shared ("pad", H, W, 64) buffer of a
+        # 64-channel layer at the same resolution would leave stale activations in them
+        pad = self._padded(H, W, Cz, tag="pad_z")
         ops.latents_to_pad(z.contiguous(), pad, c.latent_channels, H, W, Cz)
         x = self._plain("x", H * W, ch[0])
         ops.conv3x3(pad, P["decoder.conv_in.weight"], P["decoder.conv_in.bias"], x, H, W, Cz, ch[0])

@@ -4,8 +4,13 @@ What it restates: `vae.enable_tiling(); image = vae.decode(latents, return_dict=
 (fastvideo/train_grpo_flux.py:279-289) with `vae = AutoencoderKL.from_pretrained(..., subfolder="vae", torch_dtype=torch.bfloat16)`
 (:697-701) under `torch.autocast("cuda", dtype=torch.bfloat16)`.
 
-PARITY UNPINNED: `AutoencoderKL` lives in diffusers (0.32.x per the reference's requirements), which is neither importable here
-nor vendored, and the reference holds no fixture of a decoded image.  The block structure below follows the 2-D originals of the
+PINNED to the reference (tests/test_vae_oracle.py, fixtures tests/golden/vae_tiling.* produced by `gen_fixtures.py vae` running
+the reference's own code in place): the tile-size rule (its constructor, autoencoder_kl_causal_3d.py:132-139), `blend_v` /
+`blend_h` (:384-399) and the tile schedule + blended pixels of `spatial_tiled_decode` (:472-525, with a recording decoder
+stand-in) -- bit for bit, and `mixgrpo_amd/vae.py`'s tiling is held to the same fixtures.
+PARITY UNPINNED for everything inside a tile -- convolutions, GroupNorm, SiLU, the mid block's attention, upsampling, the
+channel configuration: `AutoencoderKL` lives in diffusers (0.32.x per the reference's requirements), which is neither
+importable here nor vendored, and the reference holds no fixture of a decoded image.  The block structure below follows the 2-D originals of the
 blocks the reference DOES vendor in 3-D form for its Hunyuan VAE -- same lineage, same forward order:
   * ResnetBlock:  fastvideo/models/hunyuan/vae/unet_causal_3d_blocks.py:404-462  (norm1, silu, conv1, norm2, silu, conv2,
                   optional 1x1 conv_shortcut, (input + hidden) / output_scale_factor with factor 1)

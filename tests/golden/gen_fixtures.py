@@ -554,8 +554,82 @@ def gen_sampler():
     return out
 
 
+# --------------------------------------------------------------------------- VAE tiling
+def vae_tile_standin(tile, up):
+    """The recording decoder stand-in of the tiling fixtures (a deterministic function of the latent tile, so that a test
+    can hand the SAME function to the oracle / the product): channels 0..2, nearest `up` x in H and W, plus 1/8 of the
+    tile-local row index, rounded to bf16 like a bf16 decoder's output."""
+    x = tile[:, :3].float()
+    x = x.repeat_interleave(up, dim=-2).repeat_interleave(up, dim=-1)
+    rows = torch.arange(x.shape[-2], dtype=torch.float32).view(*([1] * (x.dim() - 2)), -1, 1)
+    return (x + rows / 8).to(torch.bfloat16)
+
+
+def gen_vae_tiling():
+    """What the reference HOLDS of the VAE decode as plain Python, run in place
+    (fastvideo/models/hunyuan/vae/autoencoder_kl_causal_3d.py): the tile-size rule of `__init__` (:132-139, the reference's
+    own constructor on small channel counts), `blend_v` / `blend_h` (:384-399) on 5-D [B, C, T, H, W] tensors, and
+    `spatial_tiled_decode` (:472-525) with an identity `post_quant_conv` and the recording stand-in above as `decoder`.
+    The convolutions, GroupNorm and attention of the decoder are diffusers code (absent) and stay unpinned."""
+    for k in [k for k in sys.modules if k.split(".")[0] == "diffusers"]:
+        del sys.modules[k]
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _StubFinder())
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import fastvideo.models.hunyuan.vae.autoencoder_kl_causal_3d as A
+    C = A.AutoencoderKLCausal3D
+
+    class Holder(C):
+        pass
+
+    t, meta = {}, {"tile_sizes": [], "blend": [], "tiled": []}
+    for sample_size, nblk in ((1024, 4), (512, 4), (256, 3), (32, 2), (96, 3)):
+        h = Holder.__new__(Holder)
+        h.config = Namespace(sample_size=sample_size, block_out_channels=(8,) * nblk)
+        C.__init__(h, in_channels=3, out_channels=3, block_out_channels=(8,) * nblk, layers_per_block=1, latent_channels=4,
+                   norm_num_groups=4, sample_size=sample_size, sample_tsize=64, mid_block_add_attention=False)
+        meta["tile_sizes"].append({"sample_size": sample_size, "n_blocks": nblk, "tile_sample_min_size": h.tile_sample_min_size,
+                                   "tile_latent_min_size": h.tile_latent_min_size, "tile_overlap_factor": h.tile_overlap_factor})
+    g = torch.Generator().manual_seed(20251005)
+    h = Holder.__new__(Holder)
+    for i, (dt, shape_a, shape_b, extent) in enumerate(((torch.bfloat16, (2, 3, 1, 12, 10), (2, 3, 1, 12, 10), 8),
+                                                        (torch.bfloat16, (1, 3, 1, 6, 16), (1, 3, 1, 9, 16), 100),
+                                                        (torch.float32, (1, 2, 1, 16, 16), (1, 2, 1, 16, 16), 4),
+                                                        (torch.bfloat16, (1, 3, 1, 256, 8), (1, 3, 1, 256, 8), 256))):
+        for kind in ("v", "h"):
+            sa = shape_a if kind == "v" else shape_a[:3] + (shape_a[4], shape_a[3])
+            sb = shape_b if kind == "v" else shape_b[:3] + (shape_b[4], shape_b[3])
+            a = torch.randn(sa, generator=g).to(dt)
+            b = torch.randn(sb, generator=g).to(dt)
+            b_in = b.clone()
+            out = (C.blend_v if kind == "v" else C.blend_h)(h, a, b, extent)
+            assert out is b                                           # in place on the later tile
+            key = f"blend/{i}/{kind}"
+            t[key + "/a"], t[key + "/b"], t[key + "/out"] = a, b_in, out.clone()
+            meta["blend"].append({"key": key, "extent": extent, "dtype": str(dt)})
+    for i, (tl, ts, zshape) in enumerate(((16, 32, (1, 4, 1, 20, 28)), (16, 32, (2, 4, 1, 16, 40)), (8, 64, (1, 4, 1, 13, 9)),
+                                          (16, 128, (1, 4, 1, 33, 16)))):
+        h = Holder.__new__(Holder)
+        h.tile_latent_min_size, h.tile_sample_min_size, h.tile_overlap_factor = tl, ts, 0.25
+        calls = []
+        h.post_quant_conv = lambda x: x
+
+        def dec(tile, _up=ts // tl, _calls=calls):
+            _calls.append([int(tile.shape[-2]), int(tile.shape[-1])])
+            return vae_tile_standin(tile, _up)
+        h.decoder = dec
+        z = torch.randn(zshape, generator=g)
+        out = C.spatial_tiled_decode(h, z, return_dict=False)[0]
+        key = f"tiled/{i}"
+        t[key + "/z"], t[key + "/out"] = z, out.contiguous()
+        meta["tiled"].append({"key": key, "tile_latent_min_size": tl, "tile_sample_min_size": ts, "tile_overlap_factor": 0.25,
+                              "decoder_calls": calls, "out_shape": list(out.shape)})
+    return t, meta
+
+
 def main():
-    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer", "mmdit", "sampler"]
+    which = sys.argv[1:] or ["solver", "rollout", "windows", "trainer", "mmdit", "sampler", "vae"]
     install_light_stub()
     su = load_ref("ref_sampling_utils", "fastvideo/utils/sampling_utils.py")
     if "solver" in which:
@@ -580,6 +654,11 @@ def main():
     if "sampler" in which:
         json.dump(gen_sampler(), open(os.path.join(HERE, "sampler_schedule.json"), "w"), indent=1)
         print("sampler schedule ok")
+    if "vae" in which:
+        t, m = gen_vae_tiling()
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(HERE, "vae_tiling.safetensors"))
+        json.dump(m, open(os.path.join(HERE, "vae_tiling.json"), "w"), indent=1)
+        print("vae tiling:", len(t), "tensors")
     if "trainer" in which:
         tg = load_trainer()
         t, m = gen_trainer(tg)

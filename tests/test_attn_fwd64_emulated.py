@@ -141,3 +141,30 @@ def test_emulated_persistent_blocks_strided():
     step and wraps into the next batch), the order the XCD-interleaved launch walks."""
     rel, lse_err, _, _ = _emulate(512, "late", [0, 1, 2, 3], seed=6, B=2, H=3, first=1, nblk=4, stride=3)
     assert rel < 4e-3 and lse_err < 1e-5
+
+
+def test_emulated_walk_needs_stride_over_nq_below_heads():
+    """The walk carries the head index ONCE per step, so a stride that moves it by H or more (stride / nq >= H) stores outside
+    the workgroup's O blocks: `mgx_attn_fwd` must not dispatch such shapes to this kernel (its `walk_ok` guard; round 3's
+    advisor case S = 256, B = 3, H = 2, stride 5).  The control with stride / nq < H passes."""
+    with pytest.raises(AssertionError, match="stores outside"):
+        _emulate(256, "late", [0, 1, 2, 3], B=3, H=2, first=0, nblk=2, stride=5)
+    rel, lse_err, _, _ = _emulate(256, "late", [0, 1, 2, 3], B=3, H=2, first=0, nblk=2, stride=1)
+    assert rel < 4e-3 and lse_err < 1e-5
+
+
+def test_dispatch_guard_matches_the_walk():
+    """The host-side guard of csrc/attention.hip restated: grid = min(256, blocks), stride = grid / 8 (or grid), and the
+    64-wide kernel is taken only when stride / nq < H.  FLUX shapes pass; the advisor's failing shapes do not."""
+    def walk_ok(S, H, B):
+        nq = S // 256
+        nblk = nq * H * B
+        grid = min(256, nblk)
+        stride = grid // 8 if grid % 8 == 0 else grid
+        return stride // nq < H
+    assert walk_ok(4608, 24, 8) and walk_ok(4608, 24, 1) and walk_ok(1536, 24, 4) and walk_ok(768, 24, 7)
+    assert not walk_ok(256, 24, 11)            # stride 32, nq 1: 32 >= 24
+    assert not walk_ok(512, 16, 9)             # stride 32, nq 2: 16 >= 16
+    import re, os
+    src = open(os.path.join(os.path.dirname(__file__), "..", "mixgrpo_amd", "csrc", "attention.hip")).read()
+    assert re.search(r"walk_ok = S >= 256 && stride64 / \(S / 256\) < H", src)

@@ -69,3 +69,18 @@ def test_failed_save_leaves_no_partial_state(tmp_path):
     with pytest.raises(TypeError):
         save_resume_state(str(tmp_path), _Opt(), None, st, global_step=1)
     assert os.listdir(tmp_path) == []
+
+
+def test_resume_position_records_the_epoch(tmp_path):
+    """`checkpoint-{step}-{epoch}` with epoch > 0 is the normal case under the shipped launcher (max_train_steps per epoch,
+    a checkpoint every checkpointing_steps): the resume state carries the epoch, the position inside it and the number of
+    train steps done over all epochs; a state written before the epoch was recorded reads as epoch 0."""
+    from mixgrpo_amd.checkpoint import load_resume_position
+    save_resume_state(str(tmp_path), _Opt(), None, None, global_step=49, epoch=2, steps_done=2 * 300 + 49)
+    assert load_resume_position(str(tmp_path)) == (2, 49, 649)
+    assert load_resume_state(str(tmp_path), _Opt(seed=1)) == 49
+    raw = json.load(open(tmp_path / "trainer_state.json"))
+    del raw["epoch"], raw["steps_done"]
+    with open(tmp_path / "trainer_state.json", "w") as f:
+        json.dump(raw, f)
+    assert load_resume_position(str(tmp_path)) == (0, 49, 49)

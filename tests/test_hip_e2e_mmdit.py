@@ -174,6 +174,7 @@ def test_second_step_spends_free_memory_on_kept_ff_activations(monkeypatch):
     runs = []
     for keep_ff in ("0", "auto"):
         monkeypatch.setattr(FB, "KEEP_FF", keep_ff)
+        monkeypatch.setattr(FB, "KEEP_QKV", keep_ff)
         monkeypatch.setattr(FB, "KEEP_FF_RESERVE_GIB", 0.0)
         m = FluxTransformer2DModel(FluxConfig(**KW), device=dev)
         m.load_state_dict({k: t.to(dev) for k, t in P.items()})
@@ -185,6 +186,7 @@ def test_second_step_spends_free_memory_on_kept_ff_activations(monkeypatch):
             res.append(TG.train_one_step(ap, dev, m, None, reward, opt, _Sched(), iter([batch]), None, 1.0, [1, 2], step,
                                          {"A": 1.0}))
             kept.append(m.ff_blocks_kept())
+            assert m.qkv_blocks_kept() == kept[-1]          # FF pre-activations and QKV outputs are handed out together
         runs.append((res, kept, m.store.w32.clone() if hasattr(m.store, "w32") else m.flat_param.detach().clone()))
     assert runs[0][1] == [0, 0]
     assert runs[1][1] == [0, 2]                           # nothing in the first step, both blocks from the second on

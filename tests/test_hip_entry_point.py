@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _flags(tmp, extra):
+def _flags(tmp, extra, epochs=1):
     base = f"""--seed 714 --pretrained_model_name_or_path {tmp}/flux --vae_model_path {tmp}/flux --cache_dir {tmp}/.cache
  --data_json_path {tmp}/rl_embeddings/videos2caption.json --gradient_checkpointing --train_batch_size 1 --num_latent_t 1
  --sp_size 1 --train_sp_batch_size 1 --dataloader_num_workers 0 --gradient_accumulation_steps 2
@@ -32,7 +32,7 @@ def _flags(tmp, extra):
  --multi_reward_mix advantage_aggr --hps_weight 1.0 --clip_score_weight 1.0 --image_reward_weight 1.0 --pick_score_weight 1.0
  --unified_reward_weight 1.0 --dpm_algorithm_type null --dpm_apply_strategy post --dpm_post_compress_ratio 0.4
  --dpm_solver_order 2 --dpm_solver_type midpoint --frozen_init_timesteps -1 --wandb_key none --flow_grpo_sampling
- --mgx_max_epochs 1"""
+ --mgx_max_epochs {epochs}"""
     return base.split() + extra
 
 
@@ -45,9 +45,8 @@ def _run(flags, tmp):
     return [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
-def test_main_with_the_launchers_flags_then_resume(tmp_path):
+def _setup(tmp):
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
-    tmp = str(tmp_path)
     cfg = FluxConfig(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=4, joint_attention_dim=64,
                      pooled_projection_dim=32)
     FluxTransformer2DModel(cfg, device="cuda").init_synthetic(seed=5, std=0.05).save_pretrained(os.path.join(tmp, "flux", "transformer"))
@@ -65,6 +64,10 @@ def test_main_with_the_launchers_flags_then_resume(tmp_path):
     with open(os.path.join(root, "videos2caption.json"), "w") as f:
         json.dump(entries, f)
 
+
+def test_main_with_the_launchers_flags_then_resume(tmp_path):
+    tmp = str(tmp_path)
+    _setup(tmp)
     # uninterrupted: 3 steps, checkpoint written at the start of step 3 (weights after two steps)
     logs = _run(_flags(tmp, ["--max_train_steps", "3", "--checkpointing_steps", "3"]), tmp)
     assert [l["step"] for l in logs] == [1, 2, 3] and [l["global_step"] for l in logs] == [0, 1, 2]
@@ -87,3 +90,25 @@ def test_main_with_the_launchers_flags_then_resume(tmp_path):
     for k in ("train_loss", "grad_norm", "clip_frac", "reward_SyntheticReward"):
         assert again[0][k] == pytest.approx(logs[2][k], rel=1e-6, abs=1e-9), k
     assert not os.path.exists(os.path.join(tmp, "outputs", "part_cli_resumed", "checkpoint-3-0"))   # not rewritten
+
+
+def test_resume_from_a_checkpoint_of_a_later_epoch(tmp_path):
+    """The shipped launcher's shape in small: `max_train_steps` steps per epoch, a checkpoint every `checkpointing_steps`, so
+    `checkpoint-{step}-{epoch}` with epoch > 0 is the normal case.  Two epochs of two steps, checkpoints at every step; the
+    run resumed from `checkpoint-2-1` (taken before step 2 of epoch 1: three train steps done) continues at epoch 1, step 2,
+    global step 3, with the prompt, window and noise of the uninterrupted run -- and does not restart at epoch 0."""
+    tmp = str(tmp_path)
+    _setup(tmp)
+    logs = _run(_flags(tmp, ["--max_train_steps", "2", "--checkpointing_steps", "1"], epochs=2), tmp)
+    assert [(l["epoch"], l["step"], l["global_step"]) for l in logs] == [(0, 1, 0), (0, 2, 1), (1, 1, 2), (1, 2, 3)]
+    run_dir = os.path.join(tmp, "outputs", "part_cli")
+    ck = os.path.join(run_dir, "checkpoint-2-1")
+    st = json.load(open(os.path.join(ck, "trainer_state.json")))
+    assert (st["epoch"], st["global_step"], st["steps_done"]) == (1, 1, 3)
+    again = _run(_flags(tmp, ["--max_train_steps", "2", "--checkpointing_steps", "1", "--resume_from_checkpoint", ck,
+                              "--experiment_name", "cli_e1"], epochs=2), tmp)
+    assert [(l["epoch"], l["step"], l["global_step"]) for l in again] == [(1, 2, 3)]
+    assert again[0]["timesteps_train"] == logs[3]["timesteps_train"]
+    for k in ("train_loss", "grad_norm", "clip_frac", "reward_SyntheticReward"):
+        assert again[0][k] == pytest.approx(logs[3][k], rel=1e-6, abs=1e-9), k
+    assert not any(n.startswith("checkpoint") for n in os.listdir(os.path.join(tmp, "outputs", "part_cli_e1")))

@@ -218,3 +218,107 @@ def test_gelu_rows_is_the_gemm_epilogue_on_every_bf16_value(N):
     big = x.abs() > 1e-30                                                     # (bf16 subnormals halve with a visible rounding)
     # (sanity against torch: its tanh saturates to exactly -1 below x ~ -5.5 where the true value is still ~ -1e-8)
     assert torch.allclose(C[:, 0].float()[big], torch.nn.functional.gelu(x[big], approximate="tanh"), rtol=2.0 ** -7, atol=1e-6)
+
+
+# ---- stream-K tail (csrc/gemm.hip, sk_tail / gemm_sk_fixup_kernel): shapes whose last round is shared out along K under the
+# default cost rule.  (tiles, per-XCD tail R, slices per workgroup): 128 tiles = no whole round, R = 16, chunk 4, every tile in
+# two segments; 296 tiles = one whole round + R = 5 (chunk 2: tiles in 4-5 segments, workgroups with two segments);
+# 356 tiles with a ragged M edge = one round + R = 13 on four XCDs and 12 on the others; 576 tiles = 2 rounds + R = 8.
+SK_SHAPES = [(2048, 4096, 8192), (2048, 9472, 4096), (1024 - 17, 22784, 8192), (3072, 12288, 4096)]
+
+
+def test_stream_k_rule_splits_the_test_shapes():
+    """The cost rule of csrc/gemm.hip `launch()` restated (T = 0.0247 K us; split <=> chunk <= 8 (1 - 40 / T) / 1.45): the
+    shapes of this file's stream-K tests ARE split -- otherwise they would silently test the unsplit kernel."""
+    import math
+
+    def splits(M, N, K):
+        tiles = math.ceil(M / 256) * math.ceil(N / 256)
+        maxchunk = min(7, math.floor(8 * (1 - 40.0 / (K * 0.0247)) / 1.45))
+        q, rem = tiles // 8, tiles % 8
+        return [(cnt % 32) > 0 and math.ceil(8 * (cnt % 32) / 32) <= maxchunk for cnt in [q + (x < rem) for x in range(8)]]
+    for shp in SK_SHAPES + [(3072, 3072, 28672), (3072, 12288, 4096 + 64), (6144, 3072, 4096)]:
+        assert all(splits(*shp)), shp
+    assert not any(splits(4608, 3072, 15360))       # R = 27: nothing to gain, left whole
+
+
+@pytest.mark.parametrize("M,N,K", SK_SHAPES)
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_DGELU])
+def test_gemm_stream_k_tail(M, N, K, epi):
+    """The split launch agrees with the fp32 torch reference (same bar as the unsplit kernel), is deterministic, and agrees
+    with the unsplit launch of the same problem to fp32-summation-order accuracy."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    rpb = 1024 if epi == EPI_GATE_RES else 1 << 40
+    if epi == EPI_GATE_RES:
+        _, A_rows, A = _batched(M, K, rpb, 3, torch.bfloat16, g, 0.5)
+        C_store, C_rows, C0 = _batched(M, N, rpb, 5, torch.bfloat16, g, 1.0)
+    else:
+        A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+        A_rows = Rows.of(A)
+        C_store = torch.randn(M, N, generator=g).bfloat16().cuda()
+        C_rows, C0 = Rows.of(C_store), C_store
+    init = C_store.clone()
+    W = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    bias = (torch.randn(N, generator=g) * 0.2).bfloat16().cuda()
+    nb = (M + rpb - 1) // rpb if epi == EPI_GATE_RES else 1
+    gate = torch.randn(nb, N, generator=g).bfloat16().cuda() if epi == EPI_GATE_RES else None
+    aux = None
+    if epi in (EPI_GELU, EPI_GATE_RES):
+        aux = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    elif epi == EPI_DGELU:
+        aux = torch.randn(M, N, generator=g).bfloat16().cuda()
+    outs = []
+    assert ops.GEMM_STREAM_K
+    for sk in (True, True, False):
+        C_store.copy_(init)
+        ops.GEMM_STREAM_K = sk
+        try:
+            ops.gemm(A_rows, W, bias, C_rows, N, K, epi, gate=gate, gate_ld=N, aux=aux)
+        finally:
+            ops.GEMM_STREAM_K = True
+        torch.cuda.synchronize()
+        outs.append((C_store.clone(), None if aux is None or epi == EPI_DGELU else aux.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])                                   # deterministic
+    y = (A.float() @ W.float().t() + bias.float()).bfloat16().float()
+    amp = 0.0
+    if epi == EPI_BIAS:
+        ref = y
+    elif epi == EPI_GELU:
+        ref, amp = _gelu(y), 1.2
+    elif epi == EPI_GATE_RES:
+        gsel = gate.float()[torch.arange(M, device="cuda") // rpb]
+        ref, amp = C0.float() * 0 + init[:, :rpb].reshape(-1, N)[:M].float() + (gsel * y).bfloat16().float(), gsel.abs() + 0.01
+    else:
+        ref, amp = y * _dgelu(aux.float().cpu()).cuda(), 1.2
+    pick = (lambda t: t[:, :rpb].reshape(-1, N)[:M]) if epi == EPI_GATE_RES else (lambda t: t)
+    for C_out, aux_out in (outs[0], outs[2]):
+        _close_bf16(pick(C_out), ref.bfloat16(), y, amp)
+        if aux_out is not None:
+            _close_bf16(aux_out, y.bfloat16())
+    if epi == EPI_GATE_RES:
+        assert torch.equal(outs[0][0][:, rpb:], init[:, rpb:])                   # padding rows between batches untouched
+    # split vs unsplit: the same products, summed in a different order -- a handful of bf16 roundings may flip
+    assert (pick(outs[0][0]) != pick(outs[2][0])).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,beta", [(3072, 3072, 28672, 1.0), (3072, 12288, 4096 + 64, 1.0), (6144, 3072, 4096, 0.0)])
+def test_gemm_stream_k_f32_accumulate(M, N, K, beta):
+    """wgrad form with a split tail: 144 / 576 / 288 tiles (the 3072 x 3072 and 3072 x 12288 weight gradients at their K)."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(13)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.5).bfloat16().cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+    ref = beta * C0.double() + A.float().double() @ W.float().double().t()
+    outs = []
+    for _ in range(2):
+        C = C0.clone()
+        ops.gemm(Rows.of(A), W, None, Rows.of(C), N, K, EPI_F32_ACC, beta=beta)
+        torch.cuda.synchronize()
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    err = ((outs[0].double() - ref).norm() / ref.norm()).item()
+    assert err < 1e-5, err

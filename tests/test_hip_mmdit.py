@@ -260,9 +260,13 @@ def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
     grads = []
     # (True, "3"): additionally the FF pre-activation of the first three blocks (two double + one single) is kept and their
     # d -> 4d GEMM is replaced by an elementwise GELU in the recompute (FB.KEEP_FF)
-    for keep, keep_ff in ((True, "0"), (False, "0"), (True, "3"), (True, "99")):
+    # (..., "2") / (..., "99"): additionally the QKV projection's output of the first two / of all blocks is kept and the
+    # recompute skips the d -> 3d GEMM (FB.KEEP_QKV); with ("99", "99") the recompute pass runs no GEMM at all
+    for keep, keep_ff, keep_qkv in ((True, "0", "0"), (False, "0", "0"), (True, "3", "0"), (True, "99", "0"), (True, "1", "2"),
+                                    (True, "99", "99")):
         monkeypatch.setattr(FB, "KEEP_ACTS", keep)
         monkeypatch.setattr(FB, "KEEP_FF", keep_ff)
+        monkeypatch.setattr(FB, "KEEP_QKV", keep_qkv)
         ocfg, P, m = build_pair(small_cfg(2, 2))
         x, ehs, pooled, ids, tids, t, gd = make_inputs(2, 6, 10, 24, seed=3)
         R = torch.randn(2, 60, 64, generator=torch.Generator().manual_seed(9)).cuda()
@@ -273,6 +277,7 @@ def test_selective_saving_is_bit_identical_to_full_recompute(monkeypatch):
         assert (w.train.keep is not None) == keep
         if keep:
             assert w.train.ff_kept() == min(int(keep_ff), 4)
+            assert w.train.qkv_kept() == min(int(keep_qkv), 4)
         grads.append((out.detach().clone(), m.store.g32.clone()))
     for other in grads[1:]:
         assert torch.equal(grads[0][0], other[0])
