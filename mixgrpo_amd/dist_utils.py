@@ -7,10 +7,11 @@ gradient buffer (no per-parameter traffic, no parameter all-gathers).
 
 Gradient reduction (`GradReducer`): the flat fp32 gradient buffer is summed over the ranks in BUCKETS that follow the
 parameter store's block order.  Modes:
-  "bf16"  (default) each bucket is cast to bf16 (one HIP pass), all-reduced, and cast back into the fp32 buffer: half the
-          xGMI bytes of the fp32 form (23.8 GB instead of 47.6 GB per optimizer step for FLUX.1-dev); the sum of `world`
-          bf16 values carries a relative error of ~2^-9 per element -- AdamW's update is insensitive to it (tests/test_hip_dp.py)
-  "fp32"  the buffer itself is all-reduced in place (bit-exact sum order aside); the reference's FSDP reduces in fp32
+  "fp32"  (default) the buffer itself is all-reduced in place, like the reference's FSDP, which reduce-scatters its gradients
+          in fp32 (fastvideo/utils/fsdp_util.py:56-66): 47.6 GB per optimizer step for FLUX.1-dev
+  "bf16"  (MGX_DP_GRAD_DTYPE=bf16 / transformer.dp_grad_dtype) each bucket is cast to bf16 (one HIP pass), all-reduced, and
+          cast back into the fp32 buffer: half the xGMI bytes; the sum of `world` bf16 values carries a relative error of
+          ~2^-9 per element (two-rank test: tests/test_hip_dp.py; never measured at 8 ranks: opt-in)
 With `overlap=True` the buckets of a transformer block are launched (async, RCCL's own stream) as soon as the LAST
 micro-batch's backward has finished that block -- the reference's FSDP reduce-scatters per wrapped block during the
 backward too (fastvideo/utils/fsdp_util.py:56-66) -- and only waited for before the optimizer step.  Overlap is opt-in:
@@ -77,7 +78,10 @@ class GradReducer:
 
     def __init__(self, flat, mode=None, bucket_elems=128 * 1024 * 1024, overlap=None):
         self.flat = flat
-        self.mode = mode or os.environ.get("MGX_DP_GRAD_DTYPE", "bf16")
+        # default fp32: the reference's FSDP reduces its gradients in fp32 (fastvideo/utils/fsdp_util.py:56-66), and a ring over
+        # 8 ranks would sum seven bf16 partials.  bf16 (half the xGMI bytes) is an opt-in until an 8-GPU measurement says the
+        # bytes matter (even the fp32 ring is < 5 % of a step).
+        self.mode = mode or os.environ.get("MGX_DP_GRAD_DTYPE", "fp32")
         if self.mode not in ("bf16", "fp32"):
             raise ValueError(f"gradient all-reduce mode {self.mode!r} (expected 'bf16' or 'fp32')")
         self.overlap = bool(int(os.environ.get("MGX_DP_OVERLAP", "0"))) if overlap is None else bool(overlap)

@@ -5,6 +5,8 @@ betas (0.9, 0.999), eps 1e-8, and diffusers' get_scheduler("constant_with_warmup
 over the flat fp32 master weights / grads / moments that also refreshes the bf16 compute copy, with the
 clip-by-global-norm factor (train_grpo_flux.py:606) applied inside the same pass.
 """
+import math
+
 import torch
 
 from . import ops
@@ -58,24 +60,59 @@ class FusedAdamW:
         self.param_groups[0]["lr"] = float(sd["lr"])
 
 
-class ConstantWithWarmup:
-    """diffusers get_scheduler("constant_with_warmup"): lr * min(1, step / max(1, warmup))."""
+SCHEDULER_NAMES = ("linear", "cosine", "cosine_with_restarts", "polynomial", "constant", "constant_with_warmup")
 
-    def __init__(self, optimizer, num_warmup_steps=0, last_epoch=-1):
+
+class LambdaSchedule:
+    """diffusers `get_scheduler(name, optimizer, num_warmup_steps, num_training_steps, num_cycles, power)` as the reference
+    builds it (fastvideo/train_grpo_flux.py:726-734: `num_training_steps=1000000`, `num_cycles=args.lr_num_cycles`,
+    `power=args.lr_power`): lr = base_lr * factor(step), stepped once per optimizer step.  The factors are diffusers
+    `optimization.py`'s LambdaLR lambdas (the same formulas as transformers.optimization, against which
+    tests/test_optim_host.py holds them step by step; diffusers itself is absent: parity with it is unpinned).  As in
+    diffusers, `num_cycles` reaches only "cosine_with_restarts" ("cosine" runs its default half cycle) and `power` only
+    "polynomial" (lr_end 1e-7); "piecewise_constant" needs `step_rules`, which the reference never passes."""
+
+    def __init__(self, optimizer, name="constant", num_warmup_steps=0, num_training_steps=1000000, num_cycles=1, power=1.0):
+        if name not in SCHEDULER_NAMES:
+            raise ValueError(f"lr_scheduler {name!r} is not supported; choose one of {', '.join(SCHEDULER_NAMES)} "
+                             "(piecewise_constant needs step_rules, which the reference's get_scheduler call never passes)")
         self.opt = optimizer
-        self.warmup = int(num_warmup_steps)
+        self.name = name
+        self.warmup = int(num_warmup_steps) if name != "constant" else 0
+        self.total = int(num_training_steps)
+        self.num_cycles = num_cycles
+        self.power = power
         self.base = [g["lr"] for g in optimizer.param_groups]
         self.n = 0
         self._apply()
 
-    def _factor(self):
-        if self.n < self.warmup:
-            return float(self.n) / float(max(1.0, self.warmup))
-        return 1.0
+    def _factor(self, lr_init=None):
+        n, w, T = self.n, self.warmup, self.total
+        if self.name == "constant":
+            return 1.0
+        if n < w:
+            return float(n) / float(max(1.0 if self.name == "constant_with_warmup" else 1, w))
+        if self.name == "constant_with_warmup":
+            return 1.0
+        if self.name == "linear":
+            return max(0.0, float(T - n) / float(max(1, T - w)))
+        progress = float(n - w) / float(max(1, T - w))
+        if self.name == "cosine":
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+        if self.name == "cosine_with_restarts":
+            if progress >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(self.num_cycles) * progress) % 1.0))))
+        # polynomial
+        lr_end = 1e-7
+        if n > T:
+            return lr_end / lr_init
+        pct_remaining = 1 - (n - w) / (T - w)
+        return ((lr_init - lr_end) * pct_remaining ** self.power + lr_end) / lr_init
 
     def _apply(self):
         for g, b in zip(self.opt.param_groups, self.base):
-            g["lr"] = b * self._factor()
+            g["lr"] = b * self._factor(b)
 
     def step(self):
         self.n += 1
@@ -83,3 +120,16 @@ class ConstantWithWarmup:
 
     def get_last_lr(self):
         return [g["lr"] for g in self.opt.param_groups]
+
+
+def get_scheduler(name, optimizer, num_warmup_steps=0, num_training_steps=1000000, num_cycles=1, power=1.0, last_epoch=-1):
+    """The reference's `get_scheduler(...)` call (train_grpo_flux.py:726-734); `last_epoch` is accepted for the signature
+    (the reference always passes -1: its resume is unimplemented; ours restores `n` from the resume state)."""
+    return LambdaSchedule(optimizer, name, num_warmup_steps, num_training_steps, num_cycles, power)
+
+
+class ConstantWithWarmup(LambdaSchedule):
+    """diffusers get_scheduler("constant_with_warmup"): lr * min(1, step / max(1, warmup))."""
+
+    def __init__(self, optimizer, num_warmup_steps=0, last_epoch=-1):
+        super().__init__(optimizer, "constant_with_warmup", num_warmup_steps)

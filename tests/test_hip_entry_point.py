@@ -112,3 +112,50 @@ def test_resume_from_a_checkpoint_of_a_later_epoch(tmp_path):
     for k in ("train_loss", "grad_norm", "clip_frac", "reward_SyntheticReward"):
         assert again[0][k] == pytest.approx(logs[3][k], rel=1e-6, abs=1e-9), k
     assert not any(n.startswith("checkpoint") for n in os.listdir(os.path.join(tmp, "outputs", "part_cli_e1")))
+
+
+def test_main_builds_the_decode_stage_and_scores_with_plugged_in_reward_models(tmp_path):
+    """The reference's main() builds `AutoencoderKL.from_pretrained(<pretrained>, subfolder="vae", torch_dtype=bf16)`
+    (train_grpo_flux.py:697-701) and scores decoded images (:279-316).  Here: a tiny random-init VAE directory next to the
+    transformer, a toy reward model named on the command line (`--mgx_reward_plugin module:factory`), one train step through
+    the script -- the HIP decode runs inside the rollout and the per-class reward reaches the log -- and an `--lr_scheduler`
+    name other than the launcher's (`cosine`) is honoured, an unknown one fails with the list."""
+    from safetensors.torch import save_file
+    from oracle import vae as OV
+    tmp = str(tmp_path)
+    _setup(tmp)
+    vdir = os.path.join(tmp, "flux", "vae")
+    os.makedirs(vdir)
+    vkw = dict(block_out_channels=(64, 64), layers_per_block=1, sample_size=32)
+    json.dump({"_class_name": "AutoencoderKL", "block_out_channels": [64, 64], "layers_per_block": 1, "sample_size": 32,
+               "latent_channels": 16, "out_channels": 3, "norm_num_groups": 32, "scaling_factor": 0.3611, "shift_factor": 0.1159,
+               "mid_block_add_attention": True}, open(os.path.join(vdir, "config.json"), "w"))
+    save_file({k: v.bfloat16().contiguous() for k, v in OV.init_params(OV.VaeConfig(**vkw), seed=6).items()},
+              os.path.join(vdir, "diffusion_pytorch_model.safetensors"))
+    with open(os.path.join(tmp, "toy_rewards.py"), "w") as f:
+        f.write("def make(args):\n"
+                "    def brightness(images, prompts):\n"
+                "        assert len(images) == len(prompts) and images[0].dim() == 3 and images[0].shape[0] == 3\n"
+                "        return [float(im.float().mean()) for im in images]\n"
+                "    def contrast(images, prompts):\n"
+                "        return [float(im.float().std()) for im in images]\n"
+                "    return {'ToyBrightness': brightness, 'ToyContrast': contrast}\n")
+    env_path = tmp + os.pathsep + ROOT
+    flags = _flags(tmp, ["--max_train_steps", "1", "--checkpointing_steps", "100", "--mgx_reward_plugin", "toy_rewards:make",
+                         "--lr_scheduler", "cosine", "--lr_warmup_steps", "4"])
+    env = dict(os.environ, PYTHONPATH=env_path)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "mixgrpo_amd.train_grpo_flux"] + flags, cwd=tmp, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "VAE loaded" in r.stdout and "HIP VAE decode + ToyBrightness, ToyContrast" in r.stdout
+    logs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(logs) == 1
+    for k in ("reward_ToyBrightness", "reward_ToyContrast"):
+        assert k in logs[0] and logs[0][k] == logs[0][k] and abs(logs[0][k]) < 1e3
+    assert logs[0]["reward_ToyContrast"] > 0
+    assert logs[0]["learning_rate"] == pytest.approx(1e-4 * 0.5)          # two optimizer steps (G 4 / accum 2) into the cosine schedule's 4-step warm-up
+    bad = subprocess.run([sys.executable, "-m", "mixgrpo_amd.train_grpo_flux"] +
+                         _flags(tmp, ["--max_train_steps", "1", "--lr_scheduler", "piecewise_constant"]), cwd=tmp, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "constant_with_warmup" in bad.stderr and "cosine_with_restarts" in bad.stderr

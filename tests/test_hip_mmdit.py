@@ -408,14 +408,24 @@ def test_full_width_blocks_vs_oracle():
     assert worst[0][0] < 5e-2, worst[:8]
 
 
-@pytest.mark.parametrize("nd,ns", [(1, 1), (2, 2), (4, 8)])
+# measured (profiles/r03_depth_parity.json): forward rel-L2 5.9e-3 / 8.0e-3 / 1.03e-2 / 1.69e-2, gradient cosine
+# 0.99998 / 0.99996 / 0.99993 / 0.99981, worst single tensor 1.3e-2 / 1.7e-2 / 2.0e-2 / 3.2e-2: the bounds sit ~1.5 x above
+DEPTH_BOUNDS = {(1, 1): (9e-3, 0.99995, 2.5e-2), (2, 2): (1.2e-2, 0.9999, 3e-2), (4, 8): (1.6e-2, 0.9998, 3.5e-2),
+                (19, 38): (2.5e-2, 0.9995, 5e-2)}
+
+
+@pytest.mark.parametrize("nd,ns", [(1, 1), (2, 2), (4, 8), pytest.param(19, 38, id="flux1dev_full_depth_19+38")])
 def test_full_width_error_vs_depth(nd, ns):
-    """Forward rel-L2 and parameter-gradient cosine against the CPU oracle at FULL width (d = 3072) for 1+1, 2+2 and 4+8
-    blocks (12 residual blocks, 2.5 B parameters; FLUX.1-dev: 19 + 38), 64 image + 32 text tokens (the CPU oracle's time is
-    the weights'): how the bf16 error compounds with depth.  Numbers go to gpurun_out/r03_depth_parity.json; DESIGN.md section 2 quotes them."""
+    """Forward rel-L2 and parameter-gradient cosine against the CPU oracle at FULL width (d = 3072) for 1+1, 2+2, 4+8 blocks
+    and FLUX.1-dev's FULL depth, 19 + 38 blocks = 11.9 B parameters (round 3 ran that case as a one-off script; it is in the
+    driver-run suite now: ~130 s, ~150 GB of host memory for the fp32 oracle weights + autograd), 64 image + 32 text tokens
+    (the CPU oracle's time is the weights'): how the bf16 error compounds with depth.  Numbers go to
+    gpurun_out/r04_depth_parity.json; DESIGN.md section 2 quotes them."""
     import json
     import os
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    if (nd, ns) == (19, 38):
+        torch.set_num_threads(max(torch.get_num_threads(), min(16, os.cpu_count() or 1)))
     kw = dict(num_layers=nd, num_single_layers=ns)
     ocfg = OM.FluxConfig(**kw)
     P = OM.init_params(ocfg, seed=2, std=0.02, bias_std=0.02)
@@ -451,13 +461,18 @@ def test_full_width_error_vs_depth(nd, ns):
         worst = max(worst, ((gh - go).norm() / (go.norm() + 1e-9)).item())
     cos = dots / math.sqrt(nh * no)
     os.makedirs("gpurun_out", exist_ok=True)
-    path = os.path.join("gpurun_out", "r03_depth_parity.json")
+    path = os.path.join("gpurun_out", "r04_depth_parity.json")
     old = json.load(open(path)) if os.path.exists(path) else {}
     old[f"fwd_bwd_{nd}+{ns}"] = dict(forward_rel_l2=fwd, grad_cosine=cos, worst_tensor_rel=worst)
     json.dump(old, open(path, "w"), indent=1)
-    assert fwd < 2e-2, fwd
-    assert cos > 0.998, cos
-    assert worst < 1e-1, worst
+    b_fwd, b_cos, b_worst = DEPTH_BOUNDS[(nd, ns)]
+    assert fwd < b_fwd, fwd
+    assert cos > b_cos, cos
+    assert worst < b_worst, worst
+    del Pg, P, ref, m                                    # (19 + 38: ~150 GB of host memory and 120 GB of HBM go back now)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def test_second_forward_before_backward_is_refused():
