@@ -60,9 +60,9 @@ struct GemmArgs {
   int conv_shift;
   long conv_dy, conv_dx;
   // stream-K tail of the persistent kernel (described at gemm_pp_kernel): sk_ws = fp32 workspace for partial tiles (null: off),
-  // sk_maxchunk = split an XCD's last, partial round only if no workgroup then gets more than this many of a tile's SK_DIV slices
+  // sk_minparts = split an XCD's last, partial round only if each of its tiles can then be cut into at least this many parts
   float* sk_ws;
-  int sk_maxchunk;
+  int sk_minparts;
 };
 
 // element offset of K-tile kt inside an A row
@@ -652,28 +652,32 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 
 // ------------------------------------------------------------------------------------------ stream-K tail
 // A persistent launch takes ceil(tiles / 256) rounds, and the step is full of shapes whose last round is mostly idle: 2.25
-// rounds (the 3072 x 12288 weight gradients), 0.56 (3072 x 3072), 0.75 (the text stream), 3.375 / 4.2 (N = 3072 at micro-batch
-// 4 / 5): 0.55 s of a 13.1 s GEMM family (profiles/r03_gemm_shapes.jsonl).  So the LAST, partial round of every XCD is
-// shared out along K: each of its R tiles is cut into SK_DIV slices of K-tiles, the R * SK_DIV slices are dealt to the XCD's
-// `nw` workgroups in contiguous runs (workgroup w: slices [w R SK_DIV / nw, (w + 1) R SK_DIV / nw) -- at most two tiles), a
-// run that is not a whole tile leaves its raw fp32 accumulators in the workspace (slot 2 blockIdx + 0 | 1), and
-// gemm_sk_fixup_kernel adds a tile's segments IN K ORDER and runs the ordinary epilogue: deterministic (no atomics, no
-// flags, no spinning), and a given shape is always split the same way, so the training forward and its recompute stay
-// bit-identical.  What a split buys is (1 - chunk / SK_DIV) of a tile's K-loop, what it costs is the workspace round trip and
-// the fix-up launch; launch() only allows it when the former is clearly larger (sk_maxchunk).
-constexpr int SK_DIV = 8;
+// rounds (the 3072 x 12288 weight gradients), 0.56 (3072 x 3072), 0.375 / 0.75 (the text stream), 3.375 / 4.2 (N = 3072 at
+// micro-batch 4 / 5): 0.55 s of a 13.1 s GEMM family (profiles/r03_gemm_shapes.jsonl).  So the LAST, partial round of every XCD
+// is shared out along K, IN LOCKSTEP: with R tiles left for the XCD's nw workgroups, every tile's K range is cut into
+// P = nw / R equal parts (2 <= P <= SK_PMAX) and workgroup w = p R + r runs part p of tile r -- the R workgroups of a part walk
+// the same K-tiles at the same time, so they share their A / W panels in the XCD's L2 exactly as the workgroups of a whole
+// round do (a first version dealt contiguous runs of tile slices, every workgroup at its own K offset: nothing was shared, the
+// tail ran at the fabric's bandwidth and returned a third of what the K-loop arithmetic promised; profiles/r04_gemm_sk_ab_contiguous_runs.log vs r04_gemm_sk_ab_lockstep.log).
+// Every part leaves its raw fp32 accumulators in the workspace (slot = blockIdx) and gemm_sk_fixup_kernel adds a tile's parts
+// IN K ORDER and runs the ordinary epilogue: deterministic (no atomics, no flags, no spinning), and a given shape is always
+// split the same way, so the training forward and its recompute stay bit-identical.  What a split buys is (1 - 1 / P) of a
+// tile's K-loop, what it costs is the workspace round trip and the fix-up launch; launch() only allows it when the former is
+// clearly larger (sk_minparts).
+constexpr int SK_PMAX = 8;
 constexpr long SK_SLOT = 256L * 256;      // floats per workspace slot
 
-__host__ __device__ inline int sk_chunk(int R, int nw) { return (SK_DIV * R + nw - 1) / nw; }
-__host__ __device__ inline bool sk_on(const float* ws, int maxchunk, int R, int nw, int nkt) {
-  return ws != nullptr && R > 0 && nkt >= 4 * SK_DIV && sk_chunk(R, nw) <= maxchunk;
+__host__ __device__ inline int sk_parts(int R, int nw) { return R > 0 ? (nw / R < SK_PMAX ? nw / R : SK_PMAX) : 0; }
+__host__ __device__ inline bool sk_on(const float* ws, int minparts, int R, int nw, int nkt) {
+  const int P = sk_parts(R, nw);
+  return ws != nullptr && P >= 2 && P >= minparts && nkt >= 4 * P;
 }
 
 struct SkTail {
   int nfull;               // whole tiles of this workgroup (rounds before the tail)
-  int nseg;                // tail units: 0, 1 or 2
+  int nseg;                // tail units: 0 or 1
   int tile0, k00, k01, part0;
-  int tile1, k11;          // the second segment always starts at K-tile 0 and is always partial
+  int tile1, k11;          // (a second tail unit: unused by the lockstep dealing, kept for the unit walk's generality)
 };
 
 __device__ __forceinline__ SkTail sk_tail(const GemmArgs& g, int xcnt, int nw, int w, int nkt) {
@@ -681,25 +685,21 @@ __device__ __forceinline__ SkTail sk_tail(const GemmArgs& g, int xcnt, int nw, i
   t.nfull = xcnt / nw;
   const int R = xcnt - t.nfull * nw, base = t.nfull * nw;
   t.nseg = 0; t.tile0 = 0; t.k00 = 0; t.k01 = nkt; t.part0 = 0; t.tile1 = 0; t.k11 = nkt;
-  if (!sk_on(g.sk_ws, g.sk_maxchunk, R, nw, nkt)) {
+  if (!sk_on(g.sk_ws, g.sk_minparts, R, nw, nkt)) {
     if (w < R) { t.nseg = 1; t.tile0 = base + w; }
     return t;
   }
-  const int DR = SK_DIV * R, lo = w * DR / nw, hi = (w + 1) * DR / nw;
-  if (lo == hi) return t;
-  const int a = lo / SK_DIV, s0 = lo - a * SK_DIV, s1 = min(SK_DIV, hi - a * SK_DIV);
-  t.nseg = 1; t.tile0 = base + a;
-  t.k00 = s0 * nkt / SK_DIV; t.k01 = s1 * nkt / SK_DIV;
-  t.part0 = (s0 != 0 || s1 != SK_DIV) ? 1 : 0;
-  if (hi > (a + 1) * SK_DIV) {
-    t.nseg = 2; t.tile1 = base + a + 1;
-    t.k11 = (hi - (a + 1) * SK_DIV) * nkt / SK_DIV;
-  }
+  const int P = sk_parts(R, nw);
+  if (w >= P * R) return t;
+  const int p = w / R, r = w - p * R;
+  t.nseg = 1; t.tile0 = base + r;
+  t.k00 = p * nkt / P; t.k01 = (p + 1) * nkt / P;
+  t.part0 = 1;
   return t;
 }
 
 // One wave per (tail tile, wave slot of the main kernel): blockIdx.x = (r * 8 + xcd) * 8 + wid.  Mirrors gemm_pp_kernel's
-// tile walk and sk_tail()'s dealing; tiles that one workgroup computed whole were finished there.
+// tile walk and sk_tail()'s dealing.
 template <int EPI>
 __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   const int lane = threadIdx.x, wid = blockIdx.x & 7, xcd = (blockIdx.x >> 3) & 7, r = blockIdx.x >> 6;
@@ -708,28 +708,22 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   const int xbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
   const int xcnt = xcd < rem ? q + 1 : q;
   const int nfull = xcnt / nw, R = xcnt - nfull * nw;
-  if (r >= R || !sk_on(g.sk_ws, g.sk_maxchunk, R, nw, nkt)) return;
-  const int DR = SK_DIV * R;
-  // owner(s) = the workgroup whose run holds slice s = ceil((s + 1) nw / DR) - 1
-  const int w_first = ((r * SK_DIV + 1) * nw + DR - 1) / DR - 1;
-  const int w_last = ((r * SK_DIV + SK_DIV) * nw + DR - 1) / DR - 1;
-  if (w_first == w_last) return;                  // computed whole by one workgroup
+  if (r >= R || !sk_on(g.sk_ws, g.sk_minparts, R, nw, nkt)) return;
+  const int P = sk_parts(R, nw);
   f32x4 acc[4][8];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int w = w_first; w <= w_last; ++w) {       // ascending w = ascending K
-    const int lo = w * DR / nw, hi = (w + 1) * DR / nw;
-    if (lo == hi) continue;
-    const int seg = (lo / SK_DIV == r) ? 0 : 1;
-    const float* wsp = g.sk_ws + ((long)((w * 8 + xcd) * 2 + seg) << 16) + ((wid * 32) * 64 + lane) * 4;
+  for (int p = 0; p < P; ++p) {                    // ascending p = ascending K
+    const int w = p * R + r;
+    const float* wsp = g.sk_ws + ((long)(w * 8 + xcd) << 16) + ((wid * 32) * 64 + lane) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(wsp + (i * 8 + j) * 256);
-        acc[i][j] += p;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wsp + (i * 8 + j) * 256);
+        acc[i][j] += v;
       }
   }
   const int tl = xbeg + nfull * nw + r, band = g.band;
@@ -764,7 +758,7 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
 // against the matrix pipe's 2048 (83-85 % busy) at a clock the chip holds at 1.71-1.76 GHz under this load; the first
 // version of this loop with FOUR phases of 16 MFMAs (8 barriers per K-tile) ran 2622-2703 cycles at 1.82-1.87 GHz and
 // 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), round 1's lockstep K-loop 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, bool SK>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
   constexpr int WBASE = 3 * TB;
@@ -782,7 +776,15 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   const int xcnt = xcd < rem ? q + 1 : q;
   // ---- the workgroup's list of work units: `nfull` whole tiles (xbeg + lane_in_xcd + i * per_xcd_wg), then -- stream-K tail --
   // up to two SEGMENTS (tile, K-tile range) of the XCD's last, partial round (SkTail)
-  const SkTail sk = sk_tail(g, xcnt, per_xcd_wg, lane_in_xcd, nkt);
+  // (SK = false, every launch that splits nothing: the list is the strided tile walk and all of this folds away -- the unit
+  //  bookkeeping costs the big rollout shapes ~1 %, profiles/r04_gemm_ab_r03_r04_a.log, so they do not carry it)
+  SkTail sk;
+  if (SK) {
+    sk = sk_tail(g, xcnt, per_xcd_wg, lane_in_xcd, nkt);
+  } else {
+    sk.nfull = lane_in_xcd < xcnt ? (xcnt - lane_in_xcd + per_xcd_wg - 1) / per_xcd_wg : 0;
+    sk.nseg = 0; sk.tile0 = 0; sk.k00 = 0; sk.k01 = nkt; sk.part0 = 0; sk.tile1 = 0; sk.k11 = nkt;
+  }
   const int nunits = sk.nfull + sk.nseg;
   if (nunits == 0) return;
 
@@ -836,7 +838,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   // unit i of this workgroup -> (tile index inside the XCD's range, K-tile range, partial?)
 #define UNIT(i, T_, K0_, K1_, P_)                                                        \
   do {                                                                                     \
-    const int s_ = (i) - sk.nfull;                                                         \
+    const int s_ = SK ? (i) - sk.nfull : -1;                                               \
     T_ = s_ < 0 ? lane_in_xcd + (i) * per_xcd_wg : (s_ == 0 ? sk.tile0 : sk.tile1);       \
     K0_ = s_ < 0 ? 0 : (s_ == 0 ? sk.k00 : 0);                                             \
     K1_ = s_ < 0 ? nkt : (s_ == 0 ? sk.k01 : sk.k11);                                      \
@@ -943,10 +945,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
     asm volatile("" : "+v"(el), "+v"(ew));
     // (measured on the four-phase version and dropped: both halves running their epilogues in the SAME barrier interval --
     //  one extra barrier per half and tile -- is neutral; `s_setprio` around the MFMA sections is worth 2 %)
-    if (partial) {
-      // stream-K segment: the raw accumulators go to this workgroup's workspace slot in register order (every store
-      // instruction of a wave writes 1 KiB contiguous); gemm_sk_fixup_kernel sums a tile's segments and runs the epilogue
-      float* wsp = g.sk_ws + ((long)(blockIdx.x * 2 + (ui - sk.nfull)) << 16) + ((ew * 32) * 64 + el) * 4;
+    if (SK && partial) {
+      // stream-K part: the raw accumulators go to this workgroup's workspace slot in register order (every store
+      // instruction of a wave writes 1 KiB contiguous); gemm_sk_fixup_kernel sums a tile's parts and runs the epilogue
+      float* wsp = g.sk_ws + ((long)blockIdx.x << 16) + ((ew * 32) * 64 + el) * 4;
 #pragma unroll
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
@@ -992,7 +994,9 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (!CONV)
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
   // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
@@ -1000,33 +1004,36 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     // stream-K tail (caller gave a workspace): allowed when it shortens the launch.  A tile's K-loop takes T ~ K * 0.0247 us
-    // (2 * 256 * 256 * K FLOP at the 5.3 TFLOP/s a CU sustains in this kernel).  Unsplit, the last round takes T; split, the
-    // busiest workgroup runs chunk / SK_DIV of a K-loop -- but ~1.45 x slower per K-tile than in a whole round, because the
-    // workgroups of an XCD are then at different K offsets of different tiles and no longer share their A / W panels in L2
-    // (profiles/r04_gemm_sk_ab.log: chunk 2 of 8 returns 14 % on the 2.25-round weight gradients where the K-loop alone says
-    // 25 %; chunk >= 6 loses) -- plus ~40 us for the workspace round trip and the fix-up launch:
-    //     split  <=>  T * (1 - 1.45 * chunk / SK_DIV) > 40 us.
+    // (2 * 256 * 256 * K FLOP at the 5.3 TFLOP/s a CU sustains in this kernel).  Unsplit, the last round takes T; split P ways
+    // it takes T / P -- times a slowdown for the P-fold panel traffic of the tail (P parts x (rows + columns) panels per step
+    // against one round's) -- plus ~40 us for the workspace round trip and the fix-up launch:
+    //     split  <=>  T * (1 - slow / P) > cost.
     static const float sk_cost_us = getenv("MGX_GEMM_SK_COST_US") ? (float)atof(getenv("MGX_GEMM_SK_COST_US")) : 40.f;
-    static const float sk_slow = getenv("MGX_GEMM_SK_SLOWDOWN") ? (float)atof(getenv("MGX_GEMM_SK_SLOWDOWN")) : 1.45f;
+    static const float sk_slow = getenv("MGX_GEMM_SK_SLOWDOWN") ? (float)atof(getenv("MGX_GEMM_SK_SLOWDOWN")) : 1.25f;
     static const int sk_off = getenv("MGX_GEMM_SK") ? atoi(getenv("MGX_GEMM_SK")) == 0 : 0;
     int rmax = 0;
-    g.sk_maxchunk = 0;
-    if (g.sk_ws && !sk_off && !CONV && g.K / BK >= 4 * SK_DIV) {
+    g.sk_minparts = 0;
+    if (g.sk_ws && !sk_off && !CONV) {
       const float tile_us = (float)g.K * 0.0247f;
-      const int mc = (int)floorf((float)SK_DIV * (1.f - sk_cost_us / tile_us) / sk_slow);
-      g.sk_maxchunk = mc < 0 ? 0 : (mc > SK_DIV - 1 ? SK_DIV - 1 : mc);
+      const float room = 1.f - sk_cost_us / tile_us;                 // split <=> slow / P < room
+      g.sk_minparts = room <= 0.f ? SK_PMAX + 1 : (int)floorf(sk_slow / room) + 1;
+      if (g.sk_minparts < 2) g.sk_minparts = 2;
       const int nw = grid / 8, q = (int)(tiles_big >> 3), rem = (int)(tiles_big & 7);
       for (int x = 0; x < 8; ++x) {
         const int cnt = x < rem ? q + 1 : q, R = cnt % nw;
-        if (sk_on(g.sk_ws, g.sk_maxchunk, R, nw, g.K / BK) && R > rmax) rmax = R;
+        if (sk_on(g.sk_ws, g.sk_minparts, R, nw, g.K / BK) && R > rmax) rmax = R;
       }
     }
     if (rmax == 0) {
       g.sk_ws = nullptr;
       if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
     }
-    gemm_pp_kernel<EPI, CONV><<<grid, 512, 163840, st>>>(g);
-    if (rmax > 0) gemm_sk_fixup_kernel<EPI><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
+    if (rmax > 0) {
+      gemm_pp_kernel<EPI, false, true><<<grid, 512, 163840, st>>>(g);
+      gemm_sk_fixup_kernel<EPI><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
+    } else {
+      gemm_pp_kernel<EPI, CONV, false><<<grid, 512, 163840, st>>>(g);
+    }
   } else {
     gemm_kernel<EPI, CONV><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
@@ -1055,7 +1062,7 @@ __global__ void __launch_bounds__(256) gelu_rows_kernel(const bf16_raw* __restri
 
 }  // namespace
 
-extern "C" long mgx_gemm_sk_workspace_elems(void) { return 256L * 2 * SK_SLOT; }
+extern "C" long mgx_gemm_sk_workspace_elems(void) { return 256L * SK_SLOT; }
 
 extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
                                 uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
@@ -1081,7 +1088,7 @@ extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint
   g.ldw = ldw;
   g.beta = beta;
   g.conv_shift = -1; g.conv_dy = 0; g.conv_dx = 0;
-  g.sk_ws = sk_workspace; g.sk_maxchunk = 0;
+  g.sk_ws = sk_workspace; g.sk_minparts = 0;
   g.rowwise_ok = (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
                  (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
                  (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
@@ -1135,7 +1142,7 @@ extern "C" int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uin
   g.beta = 0.f;
   g.conv_shift = C == 64 ? 0 : (C == 128 ? 1 : (C == 256 ? 2 : 3));
   g.conv_dy = Wp * C; g.conv_dx = C;
-  g.sk_ws = nullptr; g.sk_maxchunk = 0;
+  g.sk_ws = nullptr; g.sk_minparts = 0;
   g.rowwise_ok = (Cout % 8 == 0) && (ld_out % 8 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) &&
                  (!residual || (uintptr_t)ones % 16 == 0);
   g.span32 = 1;

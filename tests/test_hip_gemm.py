@@ -220,26 +220,35 @@ def test_gelu_rows_is_the_gemm_epilogue_on_every_bf16_value(N):
     assert torch.allclose(C[:, 0].float()[big], torch.nn.functional.gelu(x[big], approximate="tanh"), rtol=2.0 ** -7, atol=1e-6)
 
 
-# ---- stream-K tail (csrc/gemm.hip, sk_tail / gemm_sk_fixup_kernel): shapes whose last round is shared out along K under the
-# default cost rule.  (tiles, per-XCD tail R, slices per workgroup): 128 tiles = no whole round, R = 16, chunk 4, every tile in
-# two segments; 296 tiles = one whole round + R = 5 (chunk 2: tiles in 4-5 segments, workgroups with two segments);
-# 356 tiles with a ragged M edge = one round + R = 13 on four XCDs and 12 on the others; 576 tiles = 2 rounds + R = 8.
+# ---- stream-K tail (csrc/gemm.hip, sk_tail / gemm_sk_fixup_kernel): shapes whose last round is split along K under the
+# default cost rule.  (tiles, per-XCD tail R, parts P = min(8, 32 // R)): 128 tiles = no whole round, R = 16, every tile in 2
+# parts; 296 tiles = one whole round + R = 5, 6 parts (30 of an XCD's 32 workgroups busy); 356 tiles with a ragged M edge =
+# one round + R = 13 on four XCDs and 12 on the others, 2 parts; 576 tiles = 2 rounds + R = 8, 4 parts.
 SK_SHAPES = [(2048, 4096, 8192), (2048, 9472, 4096), (1024 - 17, 22784, 8192), (3072, 12288, 4096)]
 
 
-def test_stream_k_rule_splits_the_test_shapes():
-    """The cost rule of csrc/gemm.hip `launch()` restated (T = 0.0247 K us; split <=> chunk <= 8 (1 - 40 / T) / 1.45): the
-    shapes of this file's stream-K tests ARE split -- otherwise they would silently test the unsplit kernel."""
+def _sk_splits(M, N, K):
+    """The cost rule of csrc/gemm.hip `launch()` restated, per XCD: T = 0.0247 K us; P = min(8, 32 // R);
+    split <=> P >= max(2, floor(1.25 / (1 - 40 / T)) + 1) and K / 64 >= 4 P."""
     import math
+    tiles = math.ceil(M / 256) * math.ceil(N / 256)
+    room = 1 - 40.0 / (K * 0.0247)
+    minparts = 9 if room <= 0 else max(2, math.floor(1.25 / room) + 1)
+    q, rem = tiles // 8, tiles % 8
+    out = []
+    for cnt in [q + (x < rem) for x in range(8)]:
+        R = cnt % 32
+        P = min(8, 32 // R) if R else 0
+        out.append(P >= 2 and P >= minparts and K // 64 >= 4 * P)
+    return out
 
-    def splits(M, N, K):
-        tiles = math.ceil(M / 256) * math.ceil(N / 256)
-        maxchunk = min(7, math.floor(8 * (1 - 40.0 / (K * 0.0247)) / 1.45))
-        q, rem = tiles // 8, tiles % 8
-        return [(cnt % 32) > 0 and math.ceil(8 * (cnt % 32) / 32) <= maxchunk for cnt in [q + (x < rem) for x in range(8)]]
-    for shp in SK_SHAPES + [(3072, 3072, 28672), (3072, 12288, 4096 + 64), (6144, 3072, 4096)]:
-        assert all(splits(*shp)), shp
-    assert not any(splits(4608, 3072, 15360))       # R = 27: nothing to gain, left whole
+
+def test_stream_k_rule_splits_the_test_shapes():
+    """The shapes of this file's stream-K tests ARE split -- otherwise they would silently test the unsplit kernel."""
+    for shp in SK_SHAPES + [(2048, 4096, 8192 + 64), (3072, 12288, 4096 + 64), (6144, 3072, 4096)]:
+        assert all(_sk_splits(*shp)), shp
+    assert not any(_sk_splits(4608, 3072, 15360))       # R = 27: cannot be cut in two, left whole
+    assert not any(_sk_splits(3072, 3072, 28672))       # R = 18 likewise
 
 
 @pytest.mark.parametrize("M,N,K", SK_SHAPES)
@@ -303,9 +312,10 @@ def test_gemm_stream_k_tail(M, N, K, epi):
     assert (pick(outs[0][0]) != pick(outs[2][0])).float().mean().item() < 2e-3
 
 
-@pytest.mark.parametrize("M,N,K,beta", [(3072, 3072, 28672, 1.0), (3072, 12288, 4096 + 64, 1.0), (6144, 3072, 4096, 0.0)])
+@pytest.mark.parametrize("M,N,K,beta", [(2048, 4096, 8192 + 64, 1.0), (3072, 12288, 4096 + 64, 1.0), (6144, 3072, 4096, 0.0)])
 def test_gemm_stream_k_f32_accumulate(M, N, K, beta):
-    """wgrad form with a split tail: 144 / 576 / 288 tiles (the 3072 x 3072 and 3072 x 12288 weight gradients at their K)."""
+    """wgrad form with a split tail: 128 tiles in 2 parts, 576 (the 3072 x 12288 weight gradients) in 4 parts of 16.25 K-tiles,
+    288 in 8 parts."""
     from mixgrpo_amd import ops
     from mixgrpo_amd.ops import Rows
     g = torch.Generator().manual_seed(13)
