@@ -159,6 +159,19 @@ int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias,
                      uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                      long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
                      long sk_workspace_elems, void* stream);
+/* TWO such problems with equal N, K, epilogue and leading dimensions in ONE launch of the persistent kernel: the text- and the
+ * image-stream Linear of a FLUX double block, which diffusers issues as separate nn.Linear calls (to_q/k/v | add_q/k/v_proj,
+ * to_out | to_add_out, ff | ff_context; call sites fastvideo/utils/sampling_utils.py:68-82, train_grpo_flux.py:134-144,600).
+ * Problem 1's M1 rows come first in the tile walk, so the text stream's few tile rows ride the image stream's rounds.
+ * Grouped when M1 % 256 == 0, the epilogue is not MGX_EPI_F32_ACC, the two A operands lie within 4 GiB of each other and so do
+ * the two W operands (same activation buffer, same block of the parameter store) and the problem is large enough for the persistent kernel; otherwise
+ * the call issues the two problems one after the other (mgx_gemm_bf16_sk) -- same results either way, bit for bit per tile. */
+int mgx_gemm_bf16_pair(const uint16_t* A1, const uint16_t* W1, const uint16_t* bias1, void* C1, const uint16_t* gate1,
+                       uint16_t* aux1, int M1, long a1_rpb, long a1_bstride, long c1_rpb, long c1_bstride,
+                       const uint16_t* A2, const uint16_t* W2, const uint16_t* bias2, void* C2, const uint16_t* gate2,
+                       uint16_t* aux2, int M2, long a2_rpb, long a2_bstride, long c2_rpb, long c2_bstride, int N, int K,
+                       long lda, long ldw, long ldc, long ldaux, long gate_ld, int epilogue, float beta,
+                       float* sk_workspace, long sk_workspace_elems, void* stream);
 
 /* out[N, ld_out] = in[M, N]^T (bf16; columns M..ld_out-1 are zero-filled) and, optionally, fp32 column sums
  * colsum_out[n] = beta*colsum_out[n] + sum_m in[m, n] (bias gradients) via a deterministic two-stage reduction;

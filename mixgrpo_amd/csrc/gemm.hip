@@ -63,7 +63,34 @@ struct GemmArgs {
   // sk_minparts = split an XCD's last, partial round only if each of its tiles can then be cut into at least this many parts
   float* sk_ws;
   int sk_minparts;
+  // second problem of a PAIR launch (mgx_gemm_bf16_pair; the text- and image-stream Linear of a double block): rows
+  // m_split.. of the tile grid (m_split % 256 == 0; 0: no pair) are rows 0.. of a problem with its own operands.  Same N, K,
+  // epilogue and leading dimensions.  A2 / W2 are reached through 32-bit offsets from A / W (both streams' operands live in the
+  // same buffers), so the K-loop is the single-problem loop; only the per-tile offsets and the epilogue's operands differ.
+  int m_split;
+  long a1_off, w1_off;    // elements from A / W (= the lower of the two problems' pointers) to problem 1's first element
+  long a2_off, w2_off;    // ... and to problem 2's
+  RowMap a2, c2;
+  void* C2;
+  const bf16_raw* bias2;
+  const bf16_raw* gate2;
+  bf16_raw* aux2;
 };
+
+// operands of the problem that tile row m0 belongs to (PAIR launches), as a GemmArgs the ordinary epilogue can take
+template <bool PAIR>
+__device__ __forceinline__ GemmArgs seg_args(const GemmArgs& g, long& m0) {
+  if (!PAIR || g.m_split == 0 || m0 < g.m_split) {
+    GemmArgs r = g;
+    if (PAIR && g.m_split) r.M = g.m_split;
+    return r;
+  }
+  GemmArgs r = g;
+  r.C = g.C2; r.c = g.c2; r.bias = g.bias2; r.gate = g.gate2; r.aux = g.aux2;
+  r.M = g.M - g.m_split;
+  m0 -= g.m_split;
+  return r;
+}
 
 // element offset of K-tile kt inside an A row
 template <bool CONV>
@@ -700,7 +727,7 @@ __device__ __forceinline__ SkTail sk_tail(const GemmArgs& g, int xcnt, int nw, i
 
 // One wave per (tail tile, wave slot of the main kernel): blockIdx.x = (r * 8 + xcd) * 8 + wid.  Mirrors gemm_pp_kernel's
 // tile walk and sk_tail()'s dealing.
-template <int EPI>
+template <int EPI, bool PAIR>
 __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   const int lane = threadIdx.x, wid = blockIdx.x & 7, xcd = (blockIdx.x >> 3) & 7, r = blockIdx.x >> 6;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, nwg = tiles_m * tiles_n, nkt = g.K / BK;
@@ -729,8 +756,10 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   const int tl = xbeg + nfull * nw + r, band = g.band;
   const int per_band = band * tiles_n, b0 = tl / per_band, rows_in_band = min(band, tiles_m - b0 * band);
   const int in_band = tl - b0 * per_band;
-  const long m0 = (long)(b0 * band + in_band % rows_in_band) * 256, n0 = (long)(in_band / rows_in_band) * 256;
-  persist_epilogue<EPI>(g, acc, wid, lane, m0, n0);
+  long m0 = (long)(b0 * band + in_band % rows_in_band) * 256;
+  const long n0 = (long)(in_band / rows_in_band) * 256;
+  const GemmArgs gl = seg_args<PAIR>(g, m0);
+  persist_epilogue<EPI>(gl, acc, wid, lane, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------ persistent ping-pong kernel
@@ -758,8 +787,9 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
 // against the matrix pipe's 2048 (83-85 % busy) at a clock the chip holds at 1.71-1.76 GHz under this load; the first
 // version of this loop with FOUR phases of 16 MFMAs (8 barriers per K-tile) ran 2622-2703 cycles at 1.82-1.87 GHz and
 // 2.5-6 % fewer TFLOP/s (profiles/r02_gemm_pp4_ab.log), round 1's lockstep K-loop 6-8 % fewer (profiles/r02_gemm_pp_ab.log).
-template <int EPI, bool CONV, bool SK>
+template <int EPI, bool CONV, int MODE>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
+  constexpr bool SK = (MODE & 1) != 0, PAIR = (MODE & 2) != 0;
   constexpr int TM = 256, TN = 256, NTHR = 512, RS = NTHR / 8, TB = TM * 128, MT = 8, NTL = 4;
   constexpr int WBASE = 3 * TB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -811,10 +841,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                     \
       long mm = M0 + lrow + k_ * RS;                                                       \
       if (mm >= g.M) mm = g.M - 1;                                                         \
-      AO[k_] = (uint32_t)((row_off(g.a, mm) + src_kc * 8) * 2);                            \
+      const bool s2_ = PAIR && g.m_split && M0 >= g.m_split;                               \
+      const long ar_ = !PAIR ? row_off(g.a, mm)                                            \
+                             : (s2_ ? row_off(g.a2, mm - g.m_split) + g.a2_off : row_off(g.a, mm) + g.a1_off); \
+      AO[k_] = (uint32_t)((ar_ + src_kc * 8) * 2);                                         \
       long nn = N0 + k_ * 64 + wrow;                                                       \
       if (nn >= g.N) nn = g.N - 1;                                                         \
-      WO[k_] = (uint32_t)((nn * g.ldw + src_kc * 8) * 2);                                  \
+      WO[k_] = (uint32_t)((nn * g.ldw + (!PAIR ? 0 : (s2_ ? g.w2_off : g.w1_off)) + src_kc * 8) * 2); \
     }                                                                                      \
   } while (0)
 #define PGLDS(base, off, off_lds) \
@@ -953,6 +986,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(wsp + (i * MT + j) * 256) = acc[i][j];
+    } else if (PAIR) {
+      long m0l = m0;
+      const GemmArgs gl = seg_args<true>(g, m0l);
+      persist_epilogue<EPI>(gl, acc, ew, el, m0l, n0);
     } else {
       persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
     }
@@ -994,11 +1031,15 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    if (!CONV)
-      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, CONV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (!CONV) {
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    }
     attr_set = true;
   }
+  const bool pair = !CONV && g.m_split != 0;
   // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
@@ -1028,13 +1069,19 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
       g.sk_ws = nullptr;
       if (tiles_big < grid) grid = (int)((tiles_big + 7) / 8 * 8);
     }
-    if (rmax > 0) {
-      gemm_pp_kernel<EPI, false, true><<<grid, 512, 163840, st>>>(g);
-      gemm_sk_fixup_kernel<EPI><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
+    if (rmax > 0 && pair) {
+      gemm_pp_kernel<EPI, false, 3><<<grid, 512, 163840, st>>>(g);
+      gemm_sk_fixup_kernel<EPI, true><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
+    } else if (rmax > 0) {
+      gemm_pp_kernel<EPI, false, 1><<<grid, 512, 163840, st>>>(g);
+      gemm_sk_fixup_kernel<EPI, false><<<rmax * 64, 64, 0, st>>>(g, grid / 8);
+    } else if (pair) {
+      gemm_pp_kernel<EPI, false, 2><<<grid, 512, 163840, st>>>(g);
     } else {
-      gemm_pp_kernel<EPI, CONV, false><<<grid, 512, 163840, st>>>(g);
+      gemm_pp_kernel<EPI, CONV, 0><<<grid, 512, 163840, st>>>(g);
     }
   } else {
+    if (pair) return 1;                   // only the persistent kernel walks two problems: the caller launches them one by one
     gemm_kernel<EPI, CONV><<<cdiv(g.M, BM) * cdiv(g.N, BN), NT, 65536, st>>>(g);
   }
   MGX_CHECK_LAUNCH();
@@ -1064,6 +1111,27 @@ __global__ void __launch_bounds__(256) gelu_rows_kernel(const bf16_raw* __restri
 
 extern "C" long mgx_gemm_sk_workspace_elems(void) { return 256L * SK_SLOT; }
 
+namespace {
+int dispatch(const GemmArgs& g, int epilogue, hipStream_t st) {
+  switch (epilogue) {
+    case EPI_BIAS: return launch<EPI_BIAS>(g, st);
+    case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU>(g, st);
+    case EPI_BIAS_GATE_RES: return launch<EPI_BIAS_GATE_RES>(g, st);
+    case EPI_F32_ACC: return launch<EPI_F32_ACC>(g, st);
+    case EPI_BIAS_MULAUX: return launch<EPI_BIAS_MULAUX>(g, st);
+  }
+  mgx_set_error("unknown GEMM epilogue");
+  return MGX_ERR_ARG;
+}
+
+bool side_ok16(int N, int M, const void* C, long ldc, long c_rpb, long c_bstride, const void* aux, long ldaux, const void* gate,
+               long gate_ld, const void* bias) {
+  return (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
+         (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) && (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) &&
+         (!bias || (uintptr_t)bias % 16 == 0);
+}
+}  // namespace
+
 extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
                                 uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                                 long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
@@ -1079,7 +1147,9 @@ extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint
   MGX_REQUIRE(!aux || ldaux % 4 == 0, "aux leading dimension must keep 8-byte alignment");
   MGX_REQUIRE(a_bstride % 8 == 0 && c_bstride % 4 == 0, "batch strides must keep alignment");
   MGX_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 8 == 0), "operands must be 16-byte aligned");
-  GemmArgs g;
+  MGX_REQUIRE(epilogue != EPI_BIAS_GATE_RES || gate, "gate-residual epilogue needs a gate");
+  MGX_REQUIRE(epilogue != EPI_BIAS_MULAUX || aux, "gelu-backward epilogue needs the saved pre-activation");
+  GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.C = C; g.gate = gate; g.aux = aux; g.ldaux = ldaux; g.gate_ld = gate_ld;
   g.M = M; g.N = N; g.K = K;
   const long RPB_MAX = 1L << 30;
@@ -1089,27 +1159,72 @@ extern "C" int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint
   g.beta = beta;
   g.conv_shift = -1; g.conv_dy = 0; g.conv_dx = 0;
   g.sk_ws = sk_workspace; g.sk_minparts = 0;
-  g.rowwise_ok = (N % 8 == 0) && (c_rpb >= M || c_rpb % 128 == 0) && (ldc % 8 == 0) && (c_bstride % 8 == 0) && ((uintptr_t)C % 16 == 0) &&
-                 (!aux || (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)) &&
-                 (!gate || (gate_ld % 8 == 0 && (uintptr_t)gate % 16 == 0)) && (!bias || (uintptr_t)bias % 16 == 0);
+  g.m_split = 0;
+  g.rowwise_ok = side_ok16(N, M, C, ldc, c_rpb, c_bstride, aux, ldaux, gate, gate_ld, bias);
   {
     const long a_last = (long)((M - 1) / a_rpb) * a_bstride + (long)((M - 1) % a_rpb) * lda + K;
     g.span32 = a_last * 2 < (1L << 32) && ((long)N * ldw) * 2 < (1L << 32);
   }
-  hipStream_t st = (hipStream_t)stream;
-  switch (epilogue) {
-    case EPI_BIAS: return launch<EPI_BIAS>(g, st);
-    case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU>(g, st);
-    case EPI_BIAS_GATE_RES:
-      MGX_REQUIRE(gate, "gate-residual epilogue needs a gate");
-      return launch<EPI_BIAS_GATE_RES>(g, st);
-    case EPI_F32_ACC: return launch<EPI_F32_ACC>(g, st);
-    case EPI_BIAS_MULAUX:
-      MGX_REQUIRE(aux, "gelu-backward epilogue needs the saved pre-activation");
-      return launch<EPI_BIAS_MULAUX>(g, st);
+  return dispatch(g, epilogue, (hipStream_t)stream);
+}
+
+// Two problems of equal N, K, epilogue and leading dimensions in ONE launch of the persistent kernel: the text- and the
+// image-stream Linear of a FLUX double block (diffusers issues them as separate nn.Linear calls,
+// fastvideo/utils/sampling_utils.py:68-82).  The tile grid's first M1 rows are problem 1, the rest problem 2 (M1 % 256 == 0),
+// so the text stream's few tile rows ride the image stream's rounds instead of occupying a third of the chip for a tile time
+// of their own.  The second problem's A / W must lie within 4 GiB of the first's (the same activation buffer / the same block of
+// the parameter store).  Whatever the persistent kernel cannot take goes out as two launches of mgx_gemm_bf16_sk: same results.
+extern "C" int mgx_gemm_bf16_pair(const uint16_t* A1, const uint16_t* W1, const uint16_t* bias1, void* C1, const uint16_t* gate1,
+                                  uint16_t* aux1, int M1, long a1_rpb, long a1_bstride, long c1_rpb, long c1_bstride,
+                                  const uint16_t* A2, const uint16_t* W2, const uint16_t* bias2, void* C2, const uint16_t* gate2,
+                                  uint16_t* aux2, int M2, long a2_rpb, long a2_bstride, long c2_rpb, long c2_bstride, int N, int K,
+                                  long lda, long ldw, long ldc, long ldaux, long gate_ld, int epilogue, float beta,
+                                  float* sk_workspace, long sk_workspace_elems, void* stream) {
+  MGX_REQUIRE(A1 && W1 && C1 && A2 && W2 && C2, "null operand");
+  MGX_REQUIRE((bias1 == nullptr) == (bias2 == nullptr) && (gate1 == nullptr) == (gate2 == nullptr) && (aux1 == nullptr) == (aux2 == nullptr),
+              "the two problems must use the same optional operands");
+  const long RPB_MAX = 1L << 30;
+  // offsets are taken from the LOWER of the two pointers (the image stream's weights precede the text stream's in the store)
+  const uint16_t* Ab = A1 < A2 ? A1 : A2;
+  const uint16_t* Wb = W1 < W2 ? W1 : W2;
+  const long a1o = A1 - Ab, a2o = A2 - Ab, w1o = W1 - Wb, w2o = W2 - Wb;
+  bool groupable = M1 > 0 && M2 > 0 && M1 % 256 == 0 && epilogue != EPI_F32_ACC && K % BK == 0 && N % 4 == 0 &&
+                   ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)W1 % 16 == 0) && ((uintptr_t)A2 % 16 == 0) && ((uintptr_t)W2 % 16 == 0) &&
+                   a2_rpb > 0 && c2_rpb > 0 && a1_rpb > 0 && c1_rpb > 0;
+  if (groupable) {
+    const long a1_last = a1o + (long)((M1 - 1) / a1_rpb) * a1_bstride + (long)((M1 - 1) % a1_rpb) * lda + K;
+    const long a2_last = a2o + (long)((M2 - 1) / a2_rpb) * a2_bstride + (long)((M2 - 1) % a2_rpb) * lda + K;
+    groupable = a1_last * 2 < (1L << 32) && a2_last * 2 < (1L << 32) && ((w1o > w2o ? w1o : w2o) + (long)N * ldw) * 2 < (1L << 32);
   }
-  mgx_set_error("unknown GEMM epilogue");
-  return MGX_ERR_ARG;
+  if (groupable) {
+    MGX_REQUIRE(!sk_workspace || (sk_workspace_elems >= mgx_gemm_sk_workspace_elems() && (uintptr_t)sk_workspace % 16 == 0),
+                "stream-K workspace too small (mgx_gemm_sk_workspace_elems) or misaligned");
+    MGX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!aux1 || ldaux % 4 == 0), "leading dimensions must keep alignment");
+    MGX_REQUIRE(epilogue != EPI_BIAS_GATE_RES || gate1, "gate-residual epilogue needs a gate");
+    MGX_REQUIRE(epilogue != EPI_BIAS_MULAUX || aux1, "gelu-backward epilogue needs the saved pre-activation");
+    GemmArgs g{};
+    g.A = Ab; g.W = Wb; g.bias = bias1; g.C = C1; g.gate = gate1; g.aux = aux1; g.ldaux = ldaux; g.gate_ld = gate_ld;
+    g.M = M1 + M2; g.N = N; g.K = K;
+    g.a = RowMap{lda, a1_rpb < RPB_MAX ? a1_rpb : RPB_MAX, a1_bstride};
+    g.c = RowMap{ldc, c1_rpb < RPB_MAX ? c1_rpb : RPB_MAX, c1_bstride};
+    g.ldw = ldw; g.beta = beta;
+    g.conv_shift = -1; g.conv_dy = 0; g.conv_dx = 0;
+    g.sk_ws = sk_workspace; g.sk_minparts = 0;
+    g.m_split = M1; g.a1_off = a1o; g.a2_off = a2o; g.w1_off = w1o; g.w2_off = w2o;
+    g.a2 = RowMap{lda, a2_rpb < RPB_MAX ? a2_rpb : RPB_MAX, a2_bstride};
+    g.c2 = RowMap{ldc, c2_rpb < RPB_MAX ? c2_rpb : RPB_MAX, c2_bstride};
+    g.C2 = C2; g.bias2 = bias2; g.gate2 = gate2; g.aux2 = aux2;
+    g.rowwise_ok = side_ok16(N, M1, C1, ldc, c1_rpb, c1_bstride, aux1, ldaux, gate1, gate_ld, bias1) &&
+                   side_ok16(N, M2, C2, ldc, c2_rpb, c2_bstride, aux2, ldaux, gate2, gate_ld, bias2);
+    g.span32 = 1;
+    const int rc = dispatch(g, epilogue, (hipStream_t)stream);
+    if (rc <= 0) return rc;               // launched (0) or failed (< 0); 1: too small for the persistent kernel
+  }
+  const int rc = mgx_gemm_bf16_sk(A1, W1, bias1, C1, gate1, aux1, ldaux, M1, N, K, lda, a1_rpb, a1_bstride, ldw, ldc, c1_rpb, c1_bstride,
+                                  gate_ld, epilogue, beta, sk_workspace, sk_workspace_elems, stream);
+  if (rc) return rc;
+  return mgx_gemm_bf16_sk(A2, W2, bias2, C2, gate2, aux2, ldaux, M2, N, K, lda, a2_rpb, a2_bstride, ldw, ldc, c2_rpb, c2_bstride, gate_ld,
+                          epilogue, beta, sk_workspace, sk_workspace_elems, stream);
 }
 
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
@@ -1142,7 +1257,7 @@ extern "C" int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uin
   g.beta = 0.f;
   g.conv_shift = C == 64 ? 0 : (C == 128 ? 1 : (C == 256 ? 2 : 3));
   g.conv_dy = Wp * C; g.conv_dx = C;
-  g.sk_ws = nullptr; g.sk_minparts = 0;
+  g.sk_ws = nullptr; g.sk_minparts = 0; g.m_split = 0;
   g.rowwise_ok = (Cout % 8 == 0) && (ld_out % 8 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) &&
                  (!residual || (uintptr_t)ones % 16 == 0);
   g.span32 = 1;

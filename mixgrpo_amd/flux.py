@@ -431,27 +431,33 @@ class FluxTransformer2DModel(torch.nn.Module):
         B = w.B
         dev = self.store.device
         mods = {}
-        streams = (("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", w.N, w.L),
-                   ("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
-                    "to_add_out", "ff_context", w.L, 0))
+        # text stream first: its rows come first in the stacked scratch buffers (nrm / qkv / hid / kept activations) and in
+        # the joint [B, S, d] residual buffer, and its weights first in the parameter store -- problem 1 of the pair launches
+        streams = (("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
+                    "to_add_out", "ff_context", w.L, 0),
+                   ("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", w.N, w.L))
         row0 = {"txt": 0, "img": w.B * w.L}     # row offsets inside the per-stream scratch buffers
+        sl = {n: slice(row0[n], row0[n] + B * r) for n, r in (("txt", w.L), ("img", w.N))}
+        W16, fused = self.W, self.store.fused
+        qkv_kept = keep is not None and "qkv" in keep           # QKV output kept by the forward: no GEMM in the recompute
+        qkv_buf = keep["qkv"] if qkv_kept else w.qkv
+        nrm1 = w.nrm if save is None else save["nrm1"]
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             if mods_in is not None:
                 m = mods_in[name]
             else:
                 m = torch.empty(B, 6 * d, dtype=BF16, device=dev)
-                ops.skinny_linear(st, self.W(f"{p}.{norm}.linear.weight"), self.W(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
+                ops.skinny_linear(st, W16(f"{p}.{norm}.linear.weight"), W16(f"{p}.{norm}.linear.bias"), m, 6 * d, d)
             mods[name] = m
             Xs = self._stream_rows(w.X if x_in is None else x_in, w, name, d)
-            M = B * rows
-            nrm = (w.nrm if save is None else save["nrm1"])[row0[name]:row0[name] + M]
-            qkv_kept = keep is not None and "qkv" in keep       # QKV output kept by the forward: no GEMM in the recompute
-            qkv = (keep["qkv"] if qkv_kept else w.qkv)[row0[name]:row0[name] + M]
-            ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm, d)
-            if not (replay and qkv_kept):
-                ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
-                         self.store.fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv), 3 * d, d)
-            ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
+            ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm1[sl[name]], d)
+        if not (replay and qkv_kept):
+            # both streams' fused QKV projections in one launch (text rows ride the image stream's rounds)
+            ops.gemm_pair(*(x for name, _, qkvn, *_ in streams for x in (
+                Rows.of(nrm1[sl[name]]), fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
+                fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv_buf[sl[name]]))), 3 * d, d)
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            ops.qk_norm_rope(qkv_buf[sl[name]], self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
                              w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         # the attention output lives in the block's keep buffer when there is one (written here, read by the backward):
@@ -459,42 +465,42 @@ class FluxTransformer2DModel(torch.nn.Module):
         O_buf = keep["O"] if keep is not None else w.O
         if not replay:
             self._attn(w, O_buf, keep["lse"] if keep is not None else (w.lse if save is not None else None), d, w.S * d)
-        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+        aux1 = aux2 = hpre = None
+        if keep is not None and not replay:
+            aux1, aux2 = keep["y_attn"], keep["y_ff"]
+        elif save is not None:
+            aux1, aux2 = save["y_attn"], save["y_ff"]
+        ff_kept = keep is not None and "hid_pre" in keep
+        if save is not None:
+            hpre = save["hid_pre"]                              # (with ff_kept this IS the kept buffer)
+        elif ff_kept:
+            hpre = keep["hid_pre"]
+        part = lambda t, name: None if t is None else t[sl[name]]
+        if not replay:
+            # attention output projections, both streams: x += gate_msa * (O @ W^T + b)
+            ops.gemm_pair(*(x for name, _, _, _, _, outn, *_ in streams for x in (
+                self._stream_rows(O_buf, w, name, d), W16(f"{p}.attn.{outn}.weight"), W16(f"{p}.attn.{outn}.bias"),
+                self._stream_rows(w.X, w, name, d))), d, d, EPI_BIAS_GATE_RES, gate1=mods["txt"][:, 2 * d:3 * d],
+                gate2=mods["img"][:, 2 * d:3 * d], gate_ld=6 * d, aux1=part(aux1, "txt"), aux2=part(aux1, "img"))
+            xm = keep["x_mid"] if keep is not None else (save["x_mid"] if save is not None else None)
+            if xm is not None:
+                xm.copy_(w.X)
+        x_mid = keep["x_mid"] if replay else w.X                 # replay: saved, no to_out GEMM in the recompute
+        nrm2 = w.nrm if save is None else save["nrm2"]
+        for name in ("txt", "img"):
             m = mods[name]
-            M = B * rows
-            sl = slice(row0[name], row0[name] + M)
-            Xs = self._stream_rows(w.X, w, name, d)
-            Os = self._stream_rows(O_buf, w, name, d)
-            nrm = (w.nrm if save is None else save["nrm2"])[sl]
-            hid = w.hid[sl]
-            aux1 = aux2 = hpre = None
-            if keep is not None and not replay:
-                aux1, aux2 = keep["y_attn"][sl], keep["y_ff"][sl]
-            elif save is not None:
-                aux1, aux2 = save["y_attn"][sl], save["y_ff"][sl]
-            if save is not None:
-                hpre = save["hid_pre"][sl]
-            xs_mid = Xs
-            if replay:
-                xs_mid = self._stream_rows(keep["x_mid"], w, name, d)       # saved: no to_out GEMM in the recompute
-            else:
-                ops.gemm(Os, self.W(f"{p}.attn.{outn}.weight"), self.W(f"{p}.attn.{outn}.bias"), Xs, d, d,
-                         EPI_BIAS_GATE_RES, gate=m[:, 2 * d:3 * d], gate_ld=6 * d, aux=aux1)
-                xm = keep["x_mid"] if keep is not None else (save["x_mid"] if save is not None else None)
-                if xm is not None:
-                    (xm[:, :w.L] if name == "txt" else xm[:, w.L:]).copy_(w.X[:, :w.L] if name == "txt" else w.X[:, w.L:])
-            ops.ln_modulate(xs_mid, m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm, d)
-            ff_kept = keep is not None and "hid_pre" in keep
-            if replay and ff_kept:                                           # pre-activation kept (`save["hid_pre"]` IS the
-                ops.gelu_rows(hpre, 4 * d, hid, 4 * d, M, 4 * d)             # kept buffer): GELU re-applied, no GEMM
-            else:
-                if hpre is None and ff_kept:
-                    hpre = keep["hid_pre"][sl]
-                ops.gemm(Rows.of(nrm), self.W(f"{p}.{ffn}.net.0.proj.weight"), self.W(f"{p}.{ffn}.net.0.proj.bias"),
-                         Rows.of(hid), 4 * d, d, EPI_BIAS_GELU, aux=hpre)
-            if not replay:                                                   # y_ff saved: no ff.net.2 GEMM in the recompute
-                ops.gemm(Rows.of(hid), self.W(f"{p}.{ffn}.net.2.weight"), self.W(f"{p}.{ffn}.net.2.bias"), Xs, d, 4 * d,
-                         EPI_BIAS_GATE_RES, gate=m[:, 5 * d:6 * d], gate_ld=6 * d, aux=aux2)
+            ops.ln_modulate(self._stream_rows(x_mid, w, name, d), m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm2[sl[name]], d)
+        if replay and ff_kept:                                   # pre-activation kept: GELU re-applied, no GEMM
+            ops.gelu_rows(hpre, 4 * d, w.hid, 4 * d, B * w.S, 4 * d)
+        else:
+            ops.gemm_pair(*(x for name, _, _, _, _, _, ffn, *_ in streams for x in (
+                Rows.of(nrm2[sl[name]]), W16(f"{p}.{ffn}.net.0.proj.weight"), W16(f"{p}.{ffn}.net.0.proj.bias"),
+                Rows.of(w.hid[sl[name]]))), 4 * d, d, EPI_BIAS_GELU, aux1=part(hpre, "txt"), aux2=part(hpre, "img"))
+        if not replay:                                           # y_ff saved: no ff.net.2 GEMM in the recompute
+            ops.gemm_pair(*(x for name, _, _, _, _, _, ffn, *_ in streams for x in (
+                Rows.of(w.hid[sl[name]]), W16(f"{p}.{ffn}.net.2.weight"), W16(f"{p}.{ffn}.net.2.bias"),
+                self._stream_rows(w.X, w, name, d))), d, 4 * d, EPI_BIAS_GATE_RES, gate1=mods["txt"][:, 5 * d:6 * d],
+                gate2=mods["img"][:, 5 * d:6 * d], gate_ld=6 * d, aux1=part(aux2, "txt"), aux2=part(aux2, "img"))
         return mods
 
     def _single_block(self, i, w, st, cos, sin, save=None, mod_in=None, keep=None, replay=False, x_in=None):

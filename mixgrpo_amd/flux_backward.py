@@ -243,6 +243,20 @@ def _dgrad(model, tr, dC: Rows, N, K, wname, out: Rows, rows=None, epi=EPI_BIAS,
     ops.gemm(dC, Wt[row_lo:row_hi], None, out, row_hi - row_lo, N, epi, aux=aux, ldaux=ldaux, gate=gate, gate_ld=0)
 
 
+def _dgrad_pair(model, tr, dC1: Rows, wname1, out1: Rows, dC2: Rows, wname2, out2: Rows, N, K, rows=None, epi=EPI_BIAS, aux1=None,
+                aux2=None, ldaux=None):
+    """`_dgrad` for the text- and the image-stream Linear of a double block in ONE launch (`ops.gemm_pair`): both transposed
+    weights side by side in the Wt scratch, problem 1 = the text stream."""
+    st = model.store
+    Wts = []
+    for j, wname in enumerate((wname1, wname2)):
+        W = st.fused(st.w16, wname, N) if rows else st.view(st.w16, wname)
+        Wt = tr.Wt[j * K * N:(j + 1) * K * N].view(K, N)
+        ops.transpose(Rows.of(W), K, Wt, N)
+        Wts.append(Wt)
+    ops.gemm_pair(dC1, Wts[0], None, out1, dC2, Wts[1], None, out2, K, N, epi, aux1=aux1, aux2=aux2, ldaux=ldaux)
+
+
 def _skinny_bwd(model, tr, dmod, x, wname, bname, N, K, dx_acc):
     """Modulation / embedder linear backward: g32[W] += dmod^T x, g32[b] += sum_b dmod, dx_acc += dmod @ W."""
     st = model.store
@@ -337,10 +351,15 @@ def _backward(model, w, tr, sv, dout):
         grad_ready(p)
 
     # ---------------- double blocks (reverse)
-    streams = (("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", N, L),
-               ("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
-                "to_add_out", "ff_context", L, 0))
+    # text stream first = problem 1 of the pair launches (its rows come first in every stacked buffer); the two streams'
+    # input-gradient GEMMs go out as one launch each, everything else per stream
+    streams = (("txt", "norm1_context", ("add_q_proj", "add_k_proj", "add_v_proj"), "norm_added_q", "norm_added_k",
+                "to_add_out", "ff_context", L, 0),
+               ("img", "norm1", ("to_q", "to_k", "to_v"), "norm_q", "norm_k", "to_out.0", "ff", N, L))
+    sl = {"txt": slice(0, B * L), "img": slice(B * L, B * S)}
     dO3 = tr.dO.view(-1)[:B * S * d].view(B, S, d)
+    dh_all = tr.dbig.view(-1)[:M * 4 * d].view(M, 4 * d)
+    dqkv_all = tr.dbig.view(-1)[:M * 3 * d].view(M, 3 * d)
     for i in reversed(range(cfg.num_layers)):
         p = f"transformer_blocks.{i}"
         mods = sv["mods"][i]
@@ -354,51 +373,47 @@ def _backward(model, w, tr, sv, dout):
                             x_in=tr.block_in[i] if kept is not None else None)
         O_b, lse_b = (kept["O"], kept["lse"]) if kept is not None else (w.O, w.lse)
         dmods = {k: torch.empty(B, 6 * d, dtype=BF16, device=dev) for k in ("img", "txt")}
+        # ---- FF branch: out = x_mid + gate_mlp * ff2(gelu(ff1(LNmod(x_mid))))
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m, dm = mods[name], dmods[name]
-            Ms = B * rows
-            r0 = row0[name]
-            dXs = srows(tr.dX, name, d)
-            sl = slice(r0, r0 + Ms)
-            # ---- FF branch: out = x_mid + gate_mlp * ff2(gelu(ff1(LNmod(x_mid))))
-            ops.gate_bwd(dXs, save["y_ff"][sl], m[:, 5 * d:6 * d], 6 * d, tr.dy[sl], dm[:, 5 * d:6 * d], B, rows, d)
-            dyr = Rows.of(tr.dy[sl])
-            hid = w.hid[sl]
-            _wgrad(model, tr, Rows.of(hid), 4 * d, dyr, d, f"{p}.{ffn}.net.2.weight", f"{p}.{ffn}.net.2.bias")
-            dh = tr.dbig.view(-1)[:M * 4 * d].view(M, 4 * d)[sl]
-            _dgrad(model, tr, dyr, d, 4 * d, f"{p}.{ffn}.net.2.weight", Rows.of(dh), epi=EPI_DGELU,
-                   aux=save["hid_pre"][sl], ldaux=4 * d)
-            nrm2 = save["nrm2"][sl]
-            _wgrad(model, tr, Rows.of(nrm2), d, Rows.of(dh), 4 * d, f"{p}.{ffn}.net.0.proj.weight",
+            ops.gate_bwd(srows(tr.dX, name, d), save["y_ff"][sl[name]], m[:, 5 * d:6 * d], 6 * d, tr.dy[sl[name]],
+                         dm[:, 5 * d:6 * d], B, rows, d)
+            _wgrad(model, tr, Rows.of(w.hid[sl[name]]), 4 * d, Rows.of(tr.dy[sl[name]]), d, f"{p}.{ffn}.net.2.weight",
+                   f"{p}.{ffn}.net.2.bias")
+        _dgrad_pair(model, tr, Rows.of(tr.dy[sl["txt"]]), f"{p}.ff_context.net.2.weight", Rows.of(dh_all[sl["txt"]]),
+                    Rows.of(tr.dy[sl["img"]]), f"{p}.ff.net.2.weight", Rows.of(dh_all[sl["img"]]), d, 4 * d, epi=EPI_DGELU,
+                    aux1=save["hid_pre"][sl["txt"]], aux2=save["hid_pre"][sl["img"]], ldaux=4 * d)
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            _wgrad(model, tr, Rows.of(save["nrm2"][sl[name]]), d, Rows.of(dh_all[sl[name]]), 4 * d, f"{p}.{ffn}.net.0.proj.weight",
                    f"{p}.{ffn}.net.0.proj.bias")
-            dn = tr.dnrm[sl]
-            _dgrad(model, tr, Rows.of(dh), 4 * d, d, f"{p}.{ffn}.net.0.proj.weight", Rows.of(dn))
-            ops.ln_modulate_bwd(dn, srows(save["x_mid"], name, d), m[:, 4 * d:5 * d], 6 * d, dXs, True,
+        _dgrad_pair(model, tr, Rows.of(dh_all[sl["txt"]]), f"{p}.ff_context.net.0.proj.weight", Rows.of(tr.dnrm[sl["txt"]]),
+                    Rows.of(dh_all[sl["img"]]), f"{p}.ff.net.0.proj.weight", Rows.of(tr.dnrm[sl["img"]]), 4 * d, d)
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            m, dm = mods[name], dmods[name]
+            dXs = srows(tr.dX, name, d)
+            ops.ln_modulate_bwd(tr.dnrm[sl[name]], srows(save["x_mid"], name, d), m[:, 4 * d:5 * d], 6 * d, dXs, True,
                                 dm[:, 3 * d:4 * d], dm[:, 4 * d:5 * d], d)
             # ---- attention branch: x_mid = x_in + gate_msa * to_out(O)
-            ops.gate_bwd(dXs, save["y_attn"][sl], m[:, 2 * d:3 * d], 6 * d, tr.dy[sl], dm[:, 2 * d:3 * d], B, rows, d)
-            _wgrad(model, tr, srows(O_b, name, d), d, dyr, d, f"{p}.attn.{outn}.weight", f"{p}.attn.{outn}.bias")
-            _dgrad(model, tr, dyr, d, d, f"{p}.attn.{outn}.weight", srows(dO3, name, d))
+            ops.gate_bwd(dXs, save["y_attn"][sl[name]], m[:, 2 * d:3 * d], 6 * d, tr.dy[sl[name]], dm[:, 2 * d:3 * d], B, rows, d)
+            _wgrad(model, tr, srows(O_b, name, d), d, Rows.of(tr.dy[sl[name]]), d, f"{p}.attn.{outn}.weight",
+                   f"{p}.attn.{outn}.bias")
+        _dgrad_pair(model, tr, Rows.of(tr.dy[sl["txt"]]), f"{p}.attn.to_add_out.weight", srows(dO3, "txt", d),
+                    Rows.of(tr.dy[sl["img"]]), f"{p}.attn.to_out.0.weight", srows(dO3, "img", d), d, d)
         ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], O_b, dO3, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK, tr.dV,
                      B, H, S, Sp, d, S * d, scale)
+        qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+            ops.qk_norm_rope_bwd(qkv_b[sl[name]], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
+                                 sin, tr.dQ, tr.dK, tr.dV, dqkv_all[sl[name]], store.view(g32, f"{p}.attn.{nq}.weight"),
+                                 store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0)
+            _wgrad(model, tr, Rows.of(save["nrm1"][sl[name]]), d, Rows.of(dqkv_all[sl[name]]), 3 * d, f"{p}.attn.{qkvn[0]}.weight",
+                   f"{p}.attn.{qkvn[0]}.bias", rows=True)
+        _dgrad_pair(model, tr, Rows.of(dqkv_all[sl["txt"]]), f"{p}.attn.add_q_proj.weight", Rows.of(tr.dnrm[sl["txt"]]),
+                    Rows.of(dqkv_all[sl["img"]]), f"{p}.attn.to_q.weight", Rows.of(tr.dnrm[sl["img"]]), 3 * d, d, rows=True)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             m, dm = mods[name], dmods[name]
-            Ms = B * rows
-            r0 = row0[name]
-            sl = slice(r0, r0 + Ms)
-            dXs = srows(tr.dX, name, d)
-            dqkv = tr.dbig.view(-1)[:M * 3 * d].view(M, 3 * d)[sl]
-            qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
-            ops.qk_norm_rope_bwd(qkv_b[sl], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
-                                 sin, tr.dQ, tr.dK, tr.dV, dqkv, store.view(g32, f"{p}.attn.{nq}.weight"),
-                                 store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0)
-            nrm1 = save["nrm1"][sl]
-            _wgrad(model, tr, Rows.of(nrm1), d, Rows.of(dqkv), 3 * d, f"{p}.attn.{qkvn[0]}.weight",
-                   f"{p}.attn.{qkvn[0]}.bias", rows=True)
-            dn = tr.dnrm[sl]
-            _dgrad(model, tr, Rows.of(dqkv), 3 * d, d, f"{p}.attn.{qkvn[0]}.weight", Rows.of(dn), rows=True)
-            ops.ln_modulate_bwd(dn, srows(tr.block_in[i], name, d), m[:, d:2 * d], 6 * d, dXs, True, dm[:, 0:d],
-                                dm[:, d:2 * d], d)
+            ops.ln_modulate_bwd(tr.dnrm[sl[name]], srows(tr.block_in[i], name, d), m[:, d:2 * d], 6 * d, srows(tr.dX, name, d),
+                                True, dm[:, 0:d], dm[:, d:2 * d], d)
             _skinny_bwd(model, tr, dm, st_, f"{p}.{norm}.linear.weight", f"{p}.{norm}.linear.bias", 6 * d, d, dst)
         grad_ready(p)
 

@@ -53,6 +53,38 @@ def _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux)
                                  None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream()))
 
 
+def gemm_pair(A1: Rows, W1, bias1, C1: Rows, A2: Rows, W2, bias2, C2: Rows, N, K, epi=EPI_BIAS, gate1=None, gate2=None, gate_ld=0,
+              aux1=None, aux2=None, ldaux=None):
+    """Two Linears of equal shape in one launch (`mgx_gemm_bf16_pair`): problem 1 = the text stream, problem 2 = the image stream
+    of a FLUX double block.  Operands as in `gemm`; A1 / A2 (and W1 / W2) must come from the same buffer, problem 1 first."""
+    assert A1.M == C1.M and A2.M == C2.M and A1.ld == A2.ld and C1.ld == C2.ld
+    if not GEMM_PAIR:
+        gemm(A1, W1, bias1, C1, N, K, epi, gate=gate1, gate_ld=gate_ld, aux=aux1, ldaux=ldaux)
+        gemm(A2, W2, bias2, C2, N, K, epi, gate=gate2, gate_ld=gate_ld, aux=aux2, ldaux=ldaux)
+        return
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = _sk_workspace(C1.t.device) if GEMM_STREAM_K else None
+    dp = lambda t: None if t is None else t.data_ptr()
+    check(lib().mgx_gemm_bf16_pair(ptr(A1.t), ptr(W1), ptr(bias1), ptr(C1.t), dp(gate1), dp(aux1), A1.M, A1.rpb, A1.bstride, C1.rpb,
+                                   C1.bstride, ptr(A2.t), ptr(W2), ptr(bias2), ptr(C2.t), dp(gate2), dp(aux2), A2.M, A2.rpb,
+                                   A2.bstride, C2.rpb, C2.bstride, N, K, A1.ld, K, C1.ld, (N if ldaux is None else ldaux), gate_ld,
+                                   epi, 0.0, dp(ws), 0 if ws is None else ws.numel(), stream()))
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * (A1.M + A2.M) * N * K, (A1.M + A2.M, N, K, epi)))
+
+
+# MGX_GEMM_PAIR=1: the two streams' Linears of a double block go out as ONE launch (`mgx_gemm_bf16_pair`).  Off by default:
+# measured neutral (same box, round 4: 18.418 s per step paired vs 18.397 s unpaired, 9745 vs 12861 launches, GEMM family 1374.5
+# vs 1372.7 TFLOP/s; profiles/r04_bench_c_pair{1,0}.json.log).  The text launches' low rates (440-1240 TFLOP/s) are the idle
+# capacity of a partial round, and the merged launch ends in the same partial round: the rollout's N = 3072 pair is 192 + 1536
+# tiles = 0.75 + 6 rounds apart and 6.75 -> 7 rounds together.
+GEMM_PAIR = os.environ.get("MGX_GEMM_PAIR", "0") == "1"
+
+
 # Stream-K tail of the persistent GEMM (csrc/gemm.hip): on by default; MGX_GEMM_STREAM_K=0 calls the kernel without a
 # workspace (every tile computed whole: results independent of the batch size).
 GEMM_STREAM_K = os.environ.get("MGX_GEMM_STREAM_K", "1") != "0"

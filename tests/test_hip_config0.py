@@ -11,8 +11,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_config0_constant_reward_on_the_hip_engine():
+@pytest.mark.parametrize("stream_k", [False, True])
+def test_config0_constant_reward_on_the_hip_engine(stream_k, monkeypatch):
+    from mixgrpo_amd import ops
     from mixgrpo_amd import train_grpo_flux as TG
+    monkeypatch.setattr(ops, "GEMM_STREAM_K", stream_k)
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
     from mixgrpo_amd.grpo_states import GRPOTrainingStates
     from mixgrpo_amd.optim import ConstantWithWarmup, FusedAdamW
@@ -49,10 +52,19 @@ def test_config0_constant_reward_on_the_hip_engine():
     assert 0.0 <= res[3] < 1e-8                                               # logged KL term (kl_coeff 0): replay == rollout
     assert res[5] == {"Const": 0.5}
     assert len(trace["grad_norms"]) == 2                                      # G / accum optimizer steps
-    # first replay chunk: the rollout policy itself -> bit-identical log-probs (same kernels, same weights)
+    # first replay chunk: the rollout policy itself (same kernels, same weights).  The reference runs rollout and replay at batch
+    # 1; here the rollout runs the group as one batch and the replay a micro-batch, i.e. GEMMs of different M.  With every tile
+    # computed whole (no stream-K workspace) each output row is the same K-loop whatever M is: BIT-IDENTICAL log-probs.  With
+    # the stream-K tail (the default) the tiles of a launch's last round are summed in parts, and which tiles those are depends
+    # on M: the fp32 summation order of some rows differs, a few bf16 roundings flip, and the log-probs agree to ~1e-6 -- two
+    # orders of magnitude inside clip_range (1e-4) and three inside the north star's 1e-3.
     pairs, new_lp = trace["new_log_probs"][0]
     old = torch.stack([trace["log_probs"][i, t] for i, t in pairs])
-    assert torch.equal(new_lp, old)
+    if not stream_k:
+        assert torch.equal(new_lp, old)
+    else:
+        print(f"\nstream-K: first replay chunk vs rollout log-probs, max |diff| = {(new_lp - old).abs().max().item():.3e}")
+        assert (new_lp - old).abs().max().item() < 2e-5
     # AdamW with an all-zero gradient: m = v = 0, update 0 / (0 + eps) = 0 -> w <- w * (1 - lr * wd), twice
     w_after = m.store.w32
     assert torch.allclose(w_after, w_before * (1 - lr * wd) ** 2, rtol=1e-6, atol=1e-12)

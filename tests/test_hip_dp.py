@@ -102,8 +102,9 @@ def test_rccl_single_rank_smoke():
 
     from helpers import free_port
     code = (
-        "import os, torch, torch.distributed as dist\n"
+        "import json, os, torch, torch.distributed as dist\n"
         "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "torch.zeros(1, device=dev); torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info(dev)[0]\n"
         "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
         "from mixgrpo_amd import dist_utils as DU\n"
         "t = torch.arange(8, dtype=torch.float32, device=dev)\n"
@@ -111,6 +112,16 @@ def test_rccl_single_rank_smoke():
         "assert DU.gather_tensor(t).tolist() == list(range(8))\n"
         "b = torch.ones(1 << 20, dtype=torch.bfloat16, device=dev); w = dist.all_reduce(b, async_op=True); w.wait()\n"
         "torch.cuda.synchronize(); assert float(b.float().sum()) == float(1 << 20)\n"
+        # a gradient-bucket-sized all-reduce (128 Mi fp32 elements = 512 MiB, dist_utils.GradReducer's bucket), then what the
+        # communicator + its buffers took from the device OUTSIDE torch's allocator: the part of MGX_KEEP_FF_RESERVE_GIB that
+        # RCCL needs at world size 1 (rings over 8 ranks allocate more: unmeasured from a 1-GPU lease)
+        "g = torch.ones(128 << 20, dtype=torch.float32, device=dev); dist.all_reduce(g); torch.cuda.synchronize()\n"
+        "free1 = torch.cuda.mem_get_info(dev)[0]; held = torch.cuda.memory_reserved(dev)\n"
+        "os.makedirs('gpurun_out', exist_ok=True)\n"
+        "json.dump({'world_size': 1, 'rccl_outside_allocator_mib': round((free0 - free1 - held) / 2**20, 1),\n"
+        "           'torch_reserved_mib': round(held / 2**20, 1), 'nccl_version': list(torch.cuda.nccl.version())},\n"
+        "          open('gpurun_out/r04_rccl_footprint.json', 'w'))\n"
+        "assert (free0 - free1 - held) < 4 * 2**30, 'RCCL took more than 4 GiB at world size 1'\n"
         "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,

@@ -332,3 +332,84 @@ def test_gemm_stream_k_f32_accumulate(M, N, K, beta):
     assert torch.equal(outs[0], outs[1])
     err = ((outs[0].double() - ref).norm() / ref.norm()).item()
     assert err < 1e-5, err
+
+
+# ---- pair launches (mgx_gemm_bf16_pair): the text- and image-stream Linear of a double block as one walk of the persistent kernel
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_DGELU])
+@pytest.mark.parametrize("B,L,Nimg,N,K,swap_w", [(4, 512, 1024, 3072, 1024, False), (2, 512, 4096, 1536, 512, True), (3, 256, 2048 + 64, 2048, 256, False),
+                                                (4, 512, 1024, 3072, 4096, True)])    # the last: 288 tiles, K = 4096 -> pair AND stream-K tail
+def test_gemm_pair_equals_two_launches(epi, B, L, Nimg, N, K, swap_w):
+    """Joint [B, S, .] buffers with the text rows first (row-batched operands, as flux.py hands them over) or stacked plain
+    matrices; weights in either address order.  With the stream-K tail off every tile is computed whole by the same K-loop in
+    both forms: the pair launch must equal the two single launches BIT FOR BIT; with it on, to summation-order accuracy."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(B * 1000 + N + K + epi)
+    S = L + Nimg
+    joint_a = epi in (EPI_GATE_RES,)                         # A from a joint [B, S, K] buffer (to_out: the attention output)
+    Wboth = (torch.randn(2, N, K, generator=g) * 0.05).bfloat16().cuda()
+    Wt, Wi = (Wboth[1], Wboth[0]) if swap_w else (Wboth[0], Wboth[1])
+    bias = (torch.randn(2, N, generator=g) * 0.2).bfloat16().cuda()
+    if joint_a:
+        Abuf = (torch.randn(B, S, K, generator=g) * 0.5).bfloat16().cuda()
+        A1, A2 = Rows(Abuf, B * L, K, L, S * K), Rows(Abuf[0, L:], B * Nimg, K, Nimg, S * K)
+    else:
+        Abuf = (torch.randn(B * S, K, generator=g) * 0.5).bfloat16().cuda()
+        A1, A2 = Rows.of(Abuf[:B * L]), Rows.of(Abuf[B * L:])
+    C0 = torch.randn(B, S, N, generator=g).bfloat16().cuda()
+    gate = torch.randn(2, B, N, generator=g).bfloat16().cuda() if epi == EPI_GATE_RES else None
+    aux0 = torch.randn(B * S, N, generator=g).bfloat16().cuda() if epi == EPI_DGELU else \
+        (torch.full((B * S, N), 7.0, dtype=torch.bfloat16, device="cuda") if epi in (EPI_GELU, EPI_GATE_RES) else None)
+
+    pair_default = ops.GEMM_PAIR
+
+    def run(pair, sk):
+        C = C0.clone()
+        aux = None if aux0 is None else aux0.clone()
+        if epi == EPI_GATE_RES:                              # C joint [B, S, N], text rows first
+            C1, C2 = Rows(C, B * L, N, L, S * N), Rows(C[0, L:], B * Nimg, N, Nimg, S * N)
+        else:                                                # C stacked
+            Cs = C.view(B * S, N)
+            C1, C2 = Rows.of(Cs[:B * L]), Rows.of(Cs[B * L:])
+        a1 = None if aux is None else aux[:B * L]
+        a2 = None if aux is None else aux[B * L:]
+        g1 = None if gate is None else gate[0]
+        g2 = None if gate is None else gate[1]
+        ops.GEMM_STREAM_K, ops.GEMM_PAIR = sk, pair
+        try:
+            ops.gemm_pair(A1, Wt, bias[0], C1, A2, Wi, bias[1], C2, N, K, epi, gate1=g1, gate2=g2, gate_ld=N, aux1=a1, aux2=a2)
+        finally:
+            ops.GEMM_STREAM_K, ops.GEMM_PAIR = True, pair_default
+        torch.cuda.synchronize()
+        return C, aux
+
+    Cp, ap = run(True, False)
+    Cs_, as_ = run(False, False)
+    assert torch.equal(Cp, Cs_)
+    if aux0 is not None and epi != EPI_DGELU:
+        assert torch.equal(ap, as_)
+    Ck, _ = run(True, True)
+    assert (Ck != Cs_).float().mean().item() < 2e-3
+    # and against the fp32 reference, per stream
+    Ad = Abuf.view(B, S, K) if joint_a else None
+    for which, (W_, sl_) in enumerate(((Wt, slice(0, L)), (Wi, slice(L, S)))):
+        if joint_a:
+            a = Ad[:, sl_].reshape(-1, K)
+        else:
+            a = (Abuf[:B * L] if which == 0 else Abuf[B * L:])
+        y = (a.float() @ W_.float().t() + bias[which].float()).bfloat16().float()
+        if epi == EPI_GATE_RES:
+            rows = sl_.stop - sl_.start
+            gsel = gate[which].float().repeat_interleave(rows, dim=0)
+            ref = C0[:, sl_].reshape(-1, N).float() + (gsel * y).bfloat16().float()
+            out, amp = Cp[:, sl_].reshape(-1, N), gsel.abs() + 0.01
+        else:
+            out = Cp.view(B * S, N)[:B * L] if which == 0 else Cp.view(B * S, N)[B * L:]
+            if epi == EPI_BIAS:
+                ref, amp = y, 0.0
+            elif epi == EPI_GELU:
+                ref, amp = _gelu(y), 1.2
+            else:
+                au = aux0[:B * L] if which == 0 else aux0[B * L:]
+                ref, amp = y * _dgelu(au.float().cpu()).cuda(), 1.2
+        _close_bf16(out, ref.bfloat16(), y, amp)

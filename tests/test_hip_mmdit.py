@@ -418,7 +418,7 @@ DEPTH_BOUNDS = {(1, 1): (9e-3, 0.99995, 2.5e-2), (2, 2): (1.2e-2, 0.9999, 3e-2),
 def test_full_width_error_vs_depth(nd, ns):
     """Forward rel-L2 and parameter-gradient cosine against the CPU oracle at FULL width (d = 3072) for 1+1, 2+2, 4+8 blocks
     and FLUX.1-dev's FULL depth, 19 + 38 blocks = 11.9 B parameters (round 3 ran that case as a one-off script; it is in the
-    driver-run suite now: ~130 s, ~150 GB of host memory for the fp32 oracle weights + autograd), 64 image + 32 text tokens
+    driver-run suite now; its oracle pass runs on the device, see below), 64 image + 32 text tokens
     (the CPU oracle's time is the weights'): how the bf16 error compounds with depth.  Numbers go to
     gpurun_out/r04_depth_parity.json; DESIGN.md section 2 quotes them."""
     import json
@@ -428,9 +428,18 @@ def test_full_width_error_vs_depth(nd, ns):
         torch.set_num_threads(max(torch.get_num_threads(), min(16, os.cpu_count() or 1)))
     kw = dict(num_layers=nd, num_single_layers=ns)
     ocfg = OM.FluxConfig(**kw)
-    P = OM.init_params(ocfg, seed=2, std=0.02, bias_std=0.02)
-    m = FluxTransformer2DModel(FluxConfig(**kw), device="cuda")
-    m.load_state_dict({k: v.cuda() for k, v in P.items()})
+    # the weights are drawn ON THE DEVICE (the product's `init_synthetic`: N(0, 0.02^2) matrices and biases, norm weights
+    # 1 + N(0, 0.02^2)) and handed to the oracle: both sides hold the same fp32 values, and 11.9 B normals take a second
+    # instead of the minutes a host generator needs.
+    # Where the oracle runs: 1+1 / 2+2 / 4+8 on the host CPU like every other oracle test.  At 19 + 38 the oracle's (device-
+    # agnostic, plain fp32 torch) code runs with its tensors ON THE GPU: the same restatement, executed by torch's own fp32
+    # kernels instead of the host's BLAS -- the host pass took 130-290 s depending on the box's cores (round 3's one-off:
+    # 131 s), too much of the driver's 900 s suite limit; on the device it takes seconds.  Nothing of the product is on the
+    # oracle's side either way.
+    m = FluxTransformer2DModel(FluxConfig(**kw), device="cuda").init_synthetic(seed=2, std=0.02, bias_std=0.02)
+    odev = "cuda" if (nd, ns) == (19, 38) else "cpu"
+    P = {k: (v.detach().clone() if odev == "cuda" else v.detach().cpu()) for k, v in m.state_dict().items()}
+    assert set(P) == set(OM.param_shapes(ocfg))
     g = torch.Generator().manual_seed(4)
     B, hg, wg, L = 1, 8, 8, 32
     N = hg * wg
@@ -443,22 +452,27 @@ def test_full_width_error_vs_depth(nd, ns):
     ids = ids.reshape(N, 3)
     tids, t, gd = torch.zeros(L, 3), torch.tensor([0.954]), torch.tensor([3.5]).bfloat16()
     R = torch.randn(B, N, 64, generator=g)
-    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    ref = OM.forward(Pg, ocfg, x, ehs.float(), t, gd.float(), tids, pooled.float(), ids)
-    (ref * R).sum().backward()
+    Pg = {k: v.requires_grad_(True) for k, v in P.items()}
+    to = lambda a: a.to(odev)
+    ref = OM.forward(Pg, ocfg, to(x), to(ehs.float()), to(t), to(gd.float()), to(tids), to(pooled.float()), to(ids))
+    (ref * to(R)).sum().backward()
+    ref = ref.detach().cpu()
     m.train()
     out = m(x.cuda(), ehs.cuda(), t.cuda(), gd.cuda(), tids.cuda(), pooled.cuda(), ids.cuda())[0]
     fwd = rel_err(out, ref)
     (out.float() * R.cuda()).sum().backward()
-    dots = nh = no = 0.0
-    worst = 0.0
+    # the comparison runs on the device in fp64 (the oracle's gradient is copied over tensor by tensor): five passes over
+    # 2 x 47.6 GB are seconds there
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    worst = torch.zeros((), dtype=torch.float64, device="cuda")
     for k in P:
-        gh = m.store.view(m.store.g32, k).float().cpu()
-        go = Pg[k].grad
-        dots += (gh * go).sum().item()
-        nh += gh.pow(2).sum().item()
-        no += go.pow(2).sum().item()
-        worst = max(worst, ((gh - go).norm() / (go.norm() + 1e-9)).item())
+        gh = m.store.view(m.store.g32, k).double()
+        go = Pg[k].grad.cuda().double()
+        acc += torch.stack([(gh * go).sum(), gh.pow(2).sum(), go.pow(2).sum()])
+        worst = torch.maximum(worst, (gh - go).norm() / (go.norm() + 1e-9))
+        Pg[k].grad = None
+    dots, nh, no = acc.tolist()
+    worst = worst.item()
     cos = dots / math.sqrt(nh * no)
     os.makedirs("gpurun_out", exist_ok=True)
     path = os.path.join("gpurun_out", "r04_depth_parity.json")
@@ -495,3 +509,38 @@ def test_second_forward_before_backward_is_refused():
         out1.float().sum().backward()
     out2.float().sum().backward()                         # the latest forward's backward is fine
     assert m.flat_param.grad is not None and torch.isfinite(m.flat_param.grad).all()
+
+
+def test_pair_launches_do_not_change_a_bit_at_model_level(monkeypatch):
+    """`ops.GEMM_PAIR` (the text- and image-stream Linears of a double block as one launch, forward and input-gradient GEMMs):
+    with every tile computed whole (stream-K off) each output row is the same K-loop in both forms, so the model's output and
+    EVERY parameter gradient must be bit-identical with and without it.  Full width (d = 3072), 1 + 1 blocks, two samples of
+    512 text + 1024 image tokens: the pair launches really take the persistent kernel (M1 = 1024 rows of text, 144+ tiles)."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    monkeypatch.setattr(ops, "GEMM_STREAM_K", False)
+    m = FluxTransformer2DModel(FluxConfig(num_layers=1, num_single_layers=1), device="cuda").init_synthetic(seed=3, std=0.02,
+                                                                                                           bias_std=0.02)
+    g = torch.Generator().manual_seed(5)
+    B, hg, wg, L = 2, 32, 32, 512
+    N = hg * wg
+    x = torch.randn(B, N, 64, generator=g).cuda()
+    ehs = (0.1 * torch.randn(B, L, 4096, generator=g)).bfloat16().cuda()
+    pooled = torch.randn(B, 768, generator=g).bfloat16().cuda()
+    ids = torch.zeros(hg, wg, 3)
+    ids[..., 1] += torch.arange(hg)[:, None]
+    ids[..., 2] += torch.arange(wg)[None]
+    ids = ids.reshape(N, 3).cuda()
+    tids, t, gd = torch.zeros(L, 3).cuda(), torch.tensor([0.954, 0.5]).cuda(), torch.tensor([3.5]).bfloat16().cuda()
+    R = torch.randn(B, N, 64, generator=g).cuda()
+    m.train()
+    res = []
+    for pair in (False, True):
+        monkeypatch.setattr(ops, "GEMM_PAIR", pair)
+        m.store.ensure_grad().zero_()
+        out = m(x, ehs, t, gd, tids, pooled, ids)[0]
+        (out.float() * R).sum().backward()
+        res.append((out.detach().clone(), m.store.g32.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][1].abs().max().item() > 0
