@@ -79,6 +79,11 @@ def build(force=False, verbose=True, diagnostic_out=None, diagnostic_flags=()):
     elif diagnostic_flags:
         raise RuntimeError("extra compile flags are only accepted for a diagnostic build (diagnostic_out=...)")
     os.makedirs(obj_dir, exist_ok=True)
+    if diagnostic_out is None:
+        # object directories of earlier diagnostic builds are dead weight in every gpurun snapshot (they travel with the tree)
+        for name in os.listdir(OBJ):
+            if name.startswith("diag_") and os.path.isdir(os.path.join(OBJ, name)):
+                shutil.rmtree(os.path.join(OBJ, name), ignore_errors=True)
     _generate()
     hipcc = _hipcc()
     objs, jobs = [], []
