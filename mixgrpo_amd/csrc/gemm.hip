@@ -63,7 +63,6 @@ struct GemmArgs {
   // sk_minparts = split an XCD's last, partial round only if each of its tiles can then be cut into at least this many parts
   float* sk_ws;
   int sk_minparts;
-  int stagger;            // EXPERIMENT (MGX_GEMM_STAGGER): workgroup j of an XCD starts j * stagger shader cycles late
   // second problem of a PAIR launch (mgx_gemm_bf16_pair; the text- and image-stream Linear of a double block): rows
   // m_split.. of the tile grid (m_split % 256 == 0; 0: no pair) are rows 0.. of a problem with its own operands.  Same N, K,
   // epilogue and leading dimensions.  A2 / W2 are reached through 32-bit offsets from A / W (both streams' operands live in the
@@ -818,11 +817,6 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
   }
   const int nunits = sk.nfull + sk.nseg;
   if (nunits == 0) return;
-  if (g.stagger > 0) {      // bounded wait: the cycle counter runs on whatever the waves do
-    const long t0_ = __builtin_readcyclecounter(), d_ = (long)lane_in_xcd * g.stagger;
-    while (__builtin_readcyclecounter() - t0_ < d_) __builtin_amdgcn_s_sleep(4);
-  }
-
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const bool late = wu >= 4;
   const int lrow = tid >> 3, lkc = tid & 7;
@@ -1045,11 +1039,6 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
     attr_set = true;
   }
   const bool pair = !CONV && g.m_split != 0;
-  {
-    static const int stagger_env = getenv("MGX_GEMM_STAGGER") ? atoi(getenv("MGX_GEMM_STAGGER")) : 0;
-    static const int stagger_min_rounds = getenv("MGX_GEMM_STAGGER_MIN_ROUNDS") ? atoi(getenv("MGX_GEMM_STAGGER_MIN_ROUNDS")) : 8;
-    g.stagger = (stagger_env > 0 && tiles_big >= 256L * stagger_min_rounds) ? stagger_env : 0;
-  }
   // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
   static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
   if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
