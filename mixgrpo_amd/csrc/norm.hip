@@ -105,21 +105,40 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const bf16_raw* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_sh[i][j] = a_sc[i][j] = 0.f;
 
-  for (int rr = w; rr < LN_BWD_ROWS; rr += 4) {
-    const long rb = r0 + rr;
-    if (rb >= xm.rpb) break;
-    const long m = b * xm.rpb + rb;
-    if (m >= M) break;
+  // Row pipeline: the kernel holds 96 fp32 column accumulators + the row in fp32 (346 registers: ONE wave per SIMD, four waves
+  // per CU), so memory parallelism has to come from inside the wave: the NEXT row's operands -- x, dy and the running gradient
+  // the result is added to (it used to be read after the three reductions: a second round trip per row) -- are requested,
+  // packed, before the current row's arithmetic starts.  (Keeping the row packed and forcing two waves per SIMD spills 63-96
+  // registers: tried, not kept.)  Same operations on the same values as before: bit-identical results.
+  auto row_ok = [&](int rr) { return rr < LN_BWD_ROWS && r0 + rr < xm.rpb && b * xm.rpb + r0 + rr < M; };
+  uint4 nx[NV], ng[NV], nold[NV];
+  auto fetch = [&](int rr) {
+    const long m = b * xm.rpb + r0 + rr;
     const bf16_raw* xr = x + row_off(xm, m);
+    const bf16_raw* dxr = dx + row_off(dxm, m);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      nx[i] = *reinterpret_cast<const uint4*>(xr + (i * 64 + lane) * 8);
+      ng[i] = *reinterpret_cast<const uint4*>(dy + m * lddy + (i * 64 + lane) * 8);
+      nold[i] = accumulate ? *reinterpret_cast<const uint4*>(dxr + (i * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (row_ok(w)) fetch(w);
+  for (int rr = w; row_ok(rr); rr += 4) {
+    const long m = b * xm.rpb + r0 + rr;
+    bf16_raw* dxr = dx + row_off(dxm, m);
     float v[NV][8], g[NV][8];
+    uint4 oldp[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      unpack8(*reinterpret_cast<const uint4*>(xr + (i * 64 + lane) * 8), v[i]);
-      unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + (i * 64 + lane) * 8), g[i]);
+      unpack8(nx[i], v[i]);
+      unpack8(ng[i], g[i]);
+      oldp[i] = nold[i];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[i][j];
     }
+    if (row_ok(rr + 4)) fetch(rr + 4);               // wave-uniform
     const float Df = (float)D;
     const float mean = wave_sum(s) / Df;
     float q = 0.f;
@@ -150,7 +169,6 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const bf16_raw* __restr
     }
     c1 = wave_sum(c1) / Df;
     c2 = wave_sum(c2) / Df;
-    bf16_raw* dxr = dx + row_off(dxm, m);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       float o[8];
@@ -159,7 +177,7 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const bf16_raw* __restr
       uint4* p = reinterpret_cast<uint4*>(dxr + (i * 64 + lane) * 8);
       if (accumulate) {
         float old[8];
-        unpack8(*p, old);
+        unpack8(oldp[i], old);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += old[j];
       }
@@ -241,37 +259,54 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
   const long dmodel = (long)a.H * HD;
   const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
   const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
-  for (int i = 0; i < 16; ++i) {
-    const int tl = w * 16 + i;
-    const int t = t0 + tl;
-    if (t >= a.rows_per_batch) break;
-    const long row = (long)b * a.rows_per_batch + t;
-    const int s = a.s0 + t;
-    const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
-    const uint32_t uq = *reinterpret_cast<const uint32_t*>(base);
-    const uint32_t uk = *reinterpret_cast<const uint32_t*>(base + dmodel);
-    const uint32_t uv = *reinterpret_cast<const uint32_t*>(base + 2 * dmodel);
-    *reinterpret_cast<uint32_t*>(&vt[tl][2 * lane]) = uv;
-    const float c0 = a.cos[(long)s * HD + 2 * lane], c1 = a.cos[(long)s * HD + 2 * lane + 1];
-    const float s0 = a.sin[(long)s * HD + 2 * lane], s1 = a.sin[(long)s * HD + 2 * lane + 1];
-    const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
-    {
-      const float x0 = bf2f(uq & 0xffff), x1 = bf2f(uq >> 16);
-      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
-      const float y0 = x0 * r * wq0, y1 = x1 * r * wq1;
-      const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
-      *reinterpret_cast<uint32_t*>(a.Q + o) = pk;
-      if (EMIT_T) *reinterpret_cast<uint32_t*>(&qts[tl][2 * lane]) = pk;
+  // four tokens per pass, every load of the pass issued before the first use: a wave instruction of this kernel moves 256 bytes
+  // (one head row), so the bytes a wave keeps in flight are what its dependent chain allows -- one token at a time (three
+  // loads, two reductions, two stores, sixteen times over) was latency-bound at 4.1-4.7 TB/s (profiles/r04_trainstep_kernel_stats.csv)
+  constexpr int U = 4;
+  for (int i0 = 0; i0 < 16; i0 += U) {
+    uint32_t uq[U], uk[U], uv[U];
+    float2 cc[U], ss[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + w * 16 + i0 + u;
+      ok[u] = t < a.rows_per_batch;
+      const int tc = ok[u] ? t : a.rows_per_batch - 1;             // clamped: loaded unconditionally, never stored
+      const long row = (long)b * a.rows_per_batch + tc;
+      const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
+      uq[u] = *reinterpret_cast<const uint32_t*>(base);
+      uk[u] = *reinterpret_cast<const uint32_t*>(base + dmodel);
+      uv[u] = *reinterpret_cast<const uint32_t*>(base + 2 * dmodel);
+      const long so = (long)(a.s0 + tc) * HD + 2 * lane;
+      cc[u] = *reinterpret_cast<const float2*>(a.cos + so);
+      ss[u] = *reinterpret_cast<const float2*>(a.sin + so);
     }
-    {
-      const float x0 = bf2f(uk & 0xffff), x1 = bf2f(uk >> 16);
-      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
-      const float y0 = x0 * r * wk0, y1 = x1 * r * wk1;
-      const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
-      *reinterpret_cast<uint32_t*>(a.K + o) = pk;
-      if (EMIT_T) *reinterpret_cast<uint32_t*>(&kts[tl][2 * lane]) = pk;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;                                        // wave-uniform
+      const int tl = w * 16 + i0 + u;
+      const int s = a.s0 + t0 + tl;
+      *reinterpret_cast<uint32_t*>(&vt[tl][2 * lane]) = uv[u];
+      const float c0 = cc[u].x, c1 = cc[u].y, s0 = ss[u].x, s1 = ss[u].y;
+      const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
+      {
+        const float x0 = bf2f(uq[u] & 0xffff), x1 = bf2f(uq[u] >> 16);
+        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        const float y0 = x0 * r * wq0, y1 = x1 * r * wq1;
+        const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+        *reinterpret_cast<uint32_t*>(a.Q + o) = pk;
+        if (EMIT_T) *reinterpret_cast<uint32_t*>(&qts[tl][2 * lane]) = pk;
+      }
+      {
+        const float x0 = bf2f(uk[u] & 0xffff), x1 = bf2f(uk[u] >> 16);
+        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        const float y0 = x0 * r * wk0, y1 = x1 * r * wk1;
+        const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
+        *reinterpret_cast<uint32_t*>(a.K + o) = pk;
+        if (EMIT_T) *reinterpret_cast<uint32_t*>(&kts[tl][2 * lane]) = pk;
+      }
+      if (EMIT_T) *reinterpret_cast<uint32_t*>(a.V + o) = uv[u];
     }
-    if (EMIT_T) *reinterpret_cast<uint32_t*>(a.V + o) = uv;
   }
   __syncthreads();
   // transposed tiles: Xt[b, h, d, s0 + t0 + 0..63] <- tile[t][d]
@@ -325,37 +360,56 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
   const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
   const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
   float gq0 = 0.f, gq1 = 0.f, gk0 = 0.f, gk1 = 0.f;
-  for (int i = 0; i < 16; ++i) {
-    const int tl = w * 16 + i;
-    const int t = t0 + tl;
-    if (t >= a.rows_per_batch) break;
-    const long row = (long)b * a.rows_per_batch + t;
-    const int s = a.s0 + t;
-    const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
-    bf16_raw* obase = a.dqkv + row * a.ldo + hh * HD + 2 * lane;
-    const float c0 = a.cos[(long)s * HD + 2 * lane], c1 = a.cos[(long)s * HD + 2 * lane + 1];
-    const float s0 = a.sin[(long)s * HD + 2 * lane], s1 = a.sin[(long)s * HD + 2 * lane + 1];
-    const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
+  // four tokens per pass, all loads of the pass issued before the first use (as in the forward kernel): same arithmetic, same
+  // order of the weight-gradient sums
+  constexpr int U = 4;
+  for (int i0 = 0; i0 < 16; i0 += U) {
+    uint32_t ux[U][2], ug[U][2], uv[U];
+    float2 cc[U], ss[U];
+    bool ok[U];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const uint32_t ux = *reinterpret_cast<const uint32_t*>(base + which * dmodel);
-      const uint32_t ug = *reinterpret_cast<const uint32_t*>((which ? a.dK : a.dQ) + o);
-      const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
-      const float x0 = bf2f(ux & 0xffff), x1 = bf2f(ux >> 16);
-      const float go0 = bf2f(ug & 0xffff), go1 = bf2f(ug >> 16);
-      // rope^T: out0 = y0 c0 - y1 s0 ; out1 = y1 c1 + y0 s1
-      const float gy0 = go0 * c0 + go1 * s1;
-      const float gy1 = -go0 * s0 + go1 * c1;
-      const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
-      // y = x * r * w
-      if (which) { gk0 += gy0 * x0 * r; gk1 += gy1 * x1 * r; } else { gq0 += gy0 * x0 * r; gq1 += gy1 * x1 * r; }
-      const float gz0 = gy0 * w0, gz1 = gy1 * w1;           // grad wrt (x*r)
-      const float dot = wave_sum(gz0 * x0 + gz1 * x1) / 128.f;
-      const float dx0 = r * gz0 - x0 * r * r * r * dot;
-      const float dx1 = r * gz1 - x1 * r * r * r * dot;
-      *reinterpret_cast<uint32_t*>(obase + which * dmodel) = (uint32_t)f2bf(dx0) | ((uint32_t)f2bf(dx1) << 16);
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + w * 16 + i0 + u;
+      ok[u] = t < a.rows_per_batch;
+      const int tc = ok[u] ? t : a.rows_per_batch - 1;
+      const long row = (long)b * a.rows_per_batch + tc;
+      const int s = a.s0 + tc;
+      const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
+      const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
+      ux[u][0] = *reinterpret_cast<const uint32_t*>(base);
+      ux[u][1] = *reinterpret_cast<const uint32_t*>(base + dmodel);
+      ug[u][0] = *reinterpret_cast<const uint32_t*>(a.dQ + o);
+      ug[u][1] = *reinterpret_cast<const uint32_t*>(a.dK + o);
+      uv[u] = *reinterpret_cast<const uint32_t*>(a.dV + o);
+      cc[u] = *reinterpret_cast<const float2*>(a.cos + (long)s * HD + 2 * lane);
+      ss[u] = *reinterpret_cast<const float2*>(a.sin + (long)s * HD + 2 * lane);
     }
-    *reinterpret_cast<uint32_t*>(obase + 2 * dmodel) = *reinterpret_cast<const uint32_t*>(a.dV + o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;                                        // wave-uniform
+      const int t = t0 + w * 16 + i0 + u;
+      const long row = (long)b * a.rows_per_batch + t;
+      bf16_raw* obase = a.dqkv + row * a.ldo + hh * HD + 2 * lane;
+      const float c0 = cc[u].x, c1 = cc[u].y, s0 = ss[u].x, s1 = ss[u].y;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
+        const float x0 = bf2f(ux[u][which] & 0xffff), x1 = bf2f(ux[u][which] >> 16);
+        const float go0 = bf2f(ug[u][which] & 0xffff), go1 = bf2f(ug[u][which] >> 16);
+        // rope^T: out0 = y0 c0 - y1 s0 ; out1 = y1 c1 + y0 s1
+        const float gy0 = go0 * c0 + go1 * s1;
+        const float gy1 = -go0 * s0 + go1 * c1;
+        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        // y = x * r * w
+        if (which) { gk0 += gy0 * x0 * r; gk1 += gy1 * x1 * r; } else { gq0 += gy0 * x0 * r; gq1 += gy1 * x1 * r; }
+        const float gz0 = gy0 * w0, gz1 = gy1 * w1;           // grad wrt (x*r)
+        const float dot = wave_sum(gz0 * x0 + gz1 * x1) / 128.f;
+        const float dx0 = r * gz0 - x0 * r * r * r * dot;
+        const float dx1 = r * gz1 - x1 * r * r * r * dot;
+        *reinterpret_cast<uint32_t*>(obase + which * dmodel) = (uint32_t)f2bf(dx0) | ((uint32_t)f2bf(dx1) << 16);
+      }
+      *reinterpret_cast<uint32_t*>(obase + 2 * dmodel) = uv[u];
+    }
   }
   red[w][0][2 * lane] = gq0; red[w][0][2 * lane + 1] = gq1;
   red[w][1][2 * lane] = gk0; red[w][1][2 * lane + 1] = gk1;
