@@ -40,9 +40,13 @@ def assert_same(a, b, exact=True, rtol=2e-6, atol=2e-6):
         assert torch.allclose(a[fin].float(), b[fin].float(), rtol=rtol, atol=atol), (a[fin].float() - b[fin].float()).abs().max()
 
 
-def oracle_flux(cfg, P):
+def oracle_flux(cfg, P, device=None):
     """oracle/mmdit.forward behind the transformer call signature, parameters trainable (fp32 master weights; the
-    restatement rounds to bf16 where autocast does).  Used by the end-to-end tests on both the CPU and the GPU side."""
+    restatement rounds to bf16 where autocast does).  Used by the end-to-end tests on both the CPU and the GPU side.
+    `device`: run the MMDiT restatement's (device-agnostic, plain fp32 torch) arithmetic there -- parameters on that device,
+    inputs moved over, the output moved back -- while the trainer oracle around it stays on the host: what makes the
+    full-width, many-block cases affordable inside the suite's time limit (the host pass of a 2.5 B-parameter train step took
+    100-340 s depending on the box).  None: everything on the host."""
     import torch
     from oracle import mmdit as OM
 
@@ -50,18 +54,22 @@ def oracle_flux(cfg, P):
         def __init__(self):
             super().__init__()
             self.cfg, self.names = cfg, list(P)
-            self.params = torch.nn.ParameterList([torch.nn.Parameter(P[k].clone()) for k in self.names])
+            self.params = torch.nn.ParameterList([torch.nn.Parameter(P[k].clone() if device is None else P[k].to(device))
+                                                  for k in self.names])
             self.config = {"oracle": True}
 
         def forward(self, hidden_states, encoder_hidden_states, timestep, guidance, txt_ids, pooled_projections, img_ids,
                     joint_attention_kwargs=None, return_dict=False):
             Pd = dict(zip(self.names, self.params))
-            out = OM.forward(Pd, self.cfg, hidden_states.float(), encoder_hidden_states.float(), timestep.float(),
-                             guidance.float(), txt_ids.float(), pooled_projections.float(), img_ids.float())
-            return (out.to(torch.bfloat16),)
+            f = (lambda x: x.float()) if device is None else (lambda x: x.float().to(device))
+            out = OM.forward(Pd, self.cfg, f(hidden_states), f(encoder_hidden_states), f(timestep), f(guidance), f(txt_ids),
+                             f(pooled_projections), f(img_ids))
+            out = out.to(torch.bfloat16)
+            return (out if device is None else out.cpu(),)
 
         def clip_grad_norm_(self, max_norm):
-            return torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
+            n = torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm)
+            return n if device is None else n.cpu()
 
     return OracleFlux()
 
