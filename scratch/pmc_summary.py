@@ -18,7 +18,7 @@ for d in dirs:
                     a.setdefault(k if k != "dur" else "duration_ms", []).append(v)
 res = {}
 for name, a in acc.items():
-    if not any(s in name for s in ("attn", "fp8", "flow_", "dance_", "dpm_", "logp", "gemm_persist", "gemm_pp")):
+    if not any(s in name for s in ("attn", "fp8", "flow_", "dance_", "dpm_", "logp", "gemm_persist", "gemm_pp", "gemm_sk")):
         continue
     res[name] = {k: statistics.median(v) for k, v in a.items()}
     res[name]["dispatches_seen"] = max(len(v) for v in a.values())
