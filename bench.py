@@ -298,7 +298,7 @@ def main():
         # MI355X_MICROARCH.md prescribes for gfx950): it cannot be taken inside this process, so the committed summary
         # of the round's PMC run is quoted, per launch of the profiled shape (see profiles/README.md)
         traffic, traffic_src = None, None
-        pmc_name = next((n for n in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc_v9.json")
+        pmc_name = next((n for n in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc_v9.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         if pmc_name:
             with open(os.path.join(ROOT, "profiles", pmc_name)) as fh:

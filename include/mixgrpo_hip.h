@@ -254,6 +254,10 @@ int mgx_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
 /* y = scale * float(x) (n % 8 == 0).  With mgx_cast_f32_bf16: the bf16 gradient buckets of the data-parallel all-reduce
  * (the reference's FSDP reduce-scatters its gradients per wrapped block, fastvideo/utils/fsdp_util.py:56-66) */
 int mgx_cast_bf16_f32(const uint16_t* x, float* y, long n, float scale, void* stream);
+/* out[N, ld_out] = (bf16(gelu_tanh(float(in[M, N]))))^T, columns M..ld_out-1 zero-filled: the weight-gradient operand of
+ * ff.net.2 / proj_out formed straight from a KEPT pre-activation (the values mgx_gelu_bf16 would write, transposed; autograd of
+ * diffusers' FeedForward / FLUX single-block act_mlp under train_grpo_flux.py:600 `loss.backward()`).  N, ld_in, ld_out % 8 == 0. */
+int mgx_transpose_gelu_bf16(const uint16_t* in, uint16_t* out, int M, int N, long ld_in, long ld_out, void* stream);
 /* y[m][0..N) = bf16(gelu_tanh(float(x[m][0..N)))), rows ldx / ldy elements apart (N, ldx, ldy % 8 == 0, 16-byte aligned):
  * the activation of diffusers' FeedForward(activation_fn="gelu-approximate") / FLUX single block `act_mlp` re-created from a
  * KEPT pre-activation, bit-identical to what mgx_gemm_bf16's bias+GELU epilogue writes (it applies GELU to the bf16-rounded

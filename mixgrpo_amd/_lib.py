@@ -87,6 +87,7 @@ SIGNATURES = {
     "mgx_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
     "mgx_cast_bf16_f32": (_I, [_P, _P, _L, _F, _P]),
     "mgx_gelu_bf16": (_I, [_P, _L, _P, _L, _L, _I, _P]),
+    "mgx_transpose_gelu_bf16": (_I, [_P, _P, _I, _I, _L, _L, _P]),
     "mgx_gate_bwd_workspace": (_L, [_L, _L, _I]),
     "mgx_gate_bwd": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _P]),
     "mgx_sqnorm_workspace": (_L, []),

@@ -348,6 +348,9 @@ __global__ void __launch_bounds__(256) transpose_kernel(const bf16_raw* __restri
 // 32 v_perm, 8 x 16-byte stores): no LDS, 128-byte segments on both sides.  Block = 16x16 threads = 128x128 tile.
 __device__ __forceinline__ uint32_t lo16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100); }
 __device__ __forceinline__ uint32_t hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302); }
+// GELU = true: out = transpose(bf16(gelu_tanh(float(in)))) -- the activation a KEPT FF pre-activation stands for, formed on the
+// way into the weight-gradient operand instead of by a pass of its own (`gelu_rows_kernel` + this kernel; bit-identical values).
+template <bool GELU>
 __global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restrict__ in, bf16_raw* __restrict__ out,
                                                          float* __restrict__ part, int M, int N, RowMap im, long ldo) {
   __shared__ float cs[16][129];
@@ -367,6 +370,12 @@ __global__ void __launch_bounds__(256) transpose8_kernel(const bf16_raw* __restr
     const long m = m0 + i;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (ncol_ok && m < M) v = *reinterpret_cast<const uint4*>(in + row_off(im, m) + n0);
+    if (GELU && ncol_ok && m < M) {
+      auto gl = [](uint32_t u) {        // exactly what the bias+GELU epilogue and gelu_rows_kernel apply to the pre-activation
+        return (uint32_t)f2bf(gelu_tanh_f(bf2f(u & 0xffff))) | ((uint32_t)f2bf(gelu_tanh_f(bf2f(u >> 16))) << 16);
+      };
+      v.x = gl(v.x); v.y = gl(v.y); v.z = gl(v.z); v.w = gl(v.w);
+    }
     r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
     if (part) {
       csum[0] += bf2f(v.x & 0xffff); csum[1] += bf2f(v.x >> 16); csum[2] += bf2f(v.y & 0xffff); csum[3] += bf2f(v.y >> 16);
@@ -1277,13 +1286,24 @@ extern "C" int mgx_transpose_bf16(const uint16_t* in, uint16_t* out, float* cols
                     ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
   if (fast) {
     dim3 grid(cdiv(N, 128), cdiv(ld_out, 128));
-    transpose8_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
+    transpose8_kernel<false><<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
     if (colsum_out) colsum_finish_kernel<<<cdiv(N, 64), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 128), N, colsum_beta);
   } else {
     dim3 grid(cdiv(N, 64), cdiv(ld_out, 64));
     transpose_kernel<<<grid, 256, 0, st>>>(in, out, colsum_partial, M, N, RowMap{ld_in, in_rpb < (1L << 30) ? in_rpb : (1L << 30), in_bstride}, ld_out);
     if (colsum_out) colsum_finish_kernel<<<cdiv(N, 64), 256, 0, st>>>(colsum_partial, colsum_out, cdiv(M, 64), N, colsum_beta);
   }
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int mgx_transpose_gelu_bf16(const uint16_t* in, uint16_t* out, int M, int N, long ld_in, long ld_out, void* stream) {
+  MGX_REQUIRE(in && out && M > 0 && N > 0, "bad argument");
+  MGX_REQUIRE(ld_out >= M, "output leading dimension must cover M");
+  MGX_REQUIRE(N % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0),
+              "rows must be 16-byte addressable");
+  dim3 grid(cdiv(N, 128), cdiv(ld_out, 128));
+  transpose8_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(in, out, nullptr, M, N, RowMap{ld_in, 1L << 30, 0}, ld_out);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -490,8 +490,9 @@ class FluxTransformer2DModel(torch.nn.Module):
         for name in ("txt", "img"):
             m = mods[name]
             ops.ln_modulate(self._stream_rows(x_mid, w, name, d), m[:, 3 * d:4 * d], m[:, 4 * d:5 * d], 6 * d, nrm2[sl[name]], d)
-        if replay and ff_kept:                                   # pre-activation kept: GELU re-applied, no GEMM
-            ops.gelu_rows(hpre, 4 * d, w.hid, 4 * d, B * w.S, 4 * d)
+        if replay and ff_kept:
+            pass        # pre-activation kept: no GEMM, and no activation either -- its only reader in the backward, the weight
+                        # gradient of ff.net.2, applies GELU inside its operand transpose (flux_backward._wgrad)
         else:
             ops.gemm_pair(*(x for name, _, _, _, _, _, ffn, *_ in streams for x in (
                 Rows.of(nrm2[sl[name]]), W16(f"{p}.{ffn}.net.0.proj.weight"), W16(f"{p}.{ffn}.net.0.proj.bias"),
@@ -525,8 +526,8 @@ class FluxTransformer2DModel(torch.nn.Module):
         cat2 = w.cat.view(M, 5 * d)
         # the pre-activation (when kept) goes to columns 3d..7d of the [M, 7d] gradient staging buffer's twin
         ff_kept = keep is not None and "hid_pre" in keep
-        if replay and ff_kept:                       # pre-activation kept by the forward (`save["hid_pre"]` IS that buffer)
-            ops.gelu_rows(save["hid_pre"], 4 * d, cat2[0, d:], 5 * d, M, 4 * d)
+        if replay and ff_kept:                       # pre-activation kept by the forward (`save["hid_pre"]` IS that buffer):
+            pass                                     # no GEMM and no [O | mlp] operand (flux_backward: `lean`)
         else:
             ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
                      Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
@@ -535,7 +536,8 @@ class FluxTransformer2DModel(torch.nn.Module):
                          w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward
-            w.cat[:, :, :d].copy_(keep["O"])         # (the wgrad of proj_out reads [O | mlp] as one [M, 5d] operand)
+            if not ff_kept:
+                w.cat[:, :, :d].copy_(keep["O"])     # (the wgrad of proj_out then reads [O | mlp] as one [M, 5d] operand)
             return m
         self._attn(w, w.cat, keep["lse"] if keep is not None else (w.lse if save is not None else None), 5 * d, S * 5 * d)
         if keep is not None:

@@ -215,11 +215,14 @@ class FluxFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ helpers
-def _wgrad(model, tr, A: Rows, K, dC: Rows, N, wname, bname, rows=None):
-    """g32[W] += dC^T A ; g32[b] += colsum(dC).  `rows`: number of fused weight rows when W spans several tensors."""
+def _wgrad(model, tr, A, K, dC: Rows, N, wname, bname, rows=None):
+    """g32[W] += dC^T A ; g32[b] += colsum(dC).  `rows`: number of fused weight rows when W spans several tensors.
+    `A`: the [M, K] activation as `Rows`, or a list of column blocks `(Rows, width, gelu)` that make it up side by side --
+    `gelu`: that block is gelu_tanh of the given (kept) pre-activation, applied on the way into the transposed operand."""
     st = model.store
     g = st.ensure_grad()
-    M = A.M
+    parts = A if isinstance(A, list) else [(A, K, False)]
+    M = parts[0][0].M
     Mp = _pad64(M)
     dCt = tr.dCt[:N * Mp].view(N, Mp)
     At = tr.At[:K * Mp].view(K, Mp)
@@ -227,7 +230,11 @@ def _wgrad(model, tr, A: Rows, K, dC: Rows, N, wname, bname, rows=None):
     if bname is not None:
         gb = st.fused(g, bname, N) if rows else st.view(g, bname)
     ops.transpose(dC, N, dCt, Mp, colsum_out=gb, colsum_beta=1.0)
-    ops.transpose(A, K, At, Mp)
+    k0 = 0
+    for a_rows, width, gelu in parts:
+        ops.transpose(a_rows, width, At[k0:k0 + width], Mp, gelu=gelu)
+        k0 += width
+    assert k0 == K
     gw = st.fused(g, wname, N) if rows else st.view(g, wname)
     ops.gemm(Rows.of(dCt), At, None, Rows(gw, N, K), K, Mp, EPI_F32_ACC, beta=1.0, ldw=Mp)
 
@@ -322,22 +329,31 @@ def _backward(model, w, tr, sv, dout):
         x_in = Rows(tr.block_in[blk], M, d, S, S * d)
         dXr = Rows(tr.dX, M, d, S, S * d)
         cat2 = w.cat.view(M, 5 * d)
+        # everything kept (attention output AND the FF pre-activation): the recompute pass built no [O | mlp] operand -- the
+        # weight gradient of proj_out takes O from its keep buffer and gelu(hid_pre) formed inside the transpose, and the
+        # attention backward reads O / writes dO at row stride d
+        lean = kept is not None and "hid_pre" in kept
         # out = x + gate * y ; y = proj_out(cat)
         ops.gate_bwd(dXr, save["y_attn"], m[:, 2 * d:3 * d], 3 * d, tr.dy, dmod[:, 2 * d:3 * d], B, S, d)
         dyr = Rows.of(tr.dy)
-        _wgrad(model, tr, Rows.of(cat2), 5 * d, dyr, d, f"{p}.proj_out.weight", f"{p}.proj_out.bias")
+        a_op = [(Rows.of(kept["O"].view(M, d)), d, False), (Rows.of(kept["hid_pre"]), 4 * d, True)] if lean else Rows.of(cat2)
+        _wgrad(model, tr, a_op, 5 * d, dyr, d, f"{p}.proj_out.weight", f"{p}.proj_out.bias")
         dcat = tr.dO.view(M, 5 * d)
+        dO1 = tr.dO.view(-1)[:M * d].view(B, S, d)             # lean: dO alone, [B, S, d]
         dbig = tr.dbig                                         # [M, 7d] = [dq | dk | dv | dmlp_pre]
         # d(cat)[:, :d] = dO (attention output grad) ; d(cat)[:, d:] -> through GELU -> dbig[:, 3d:]
-        Wt_full = None
         stW = store.view(store.w16, f"{p}.proj_out.weight")
         Wt = tr.Wt[:5 * d * d].view(5 * d, d)
         ops.transpose(Rows.of(stW), 5 * d, Wt, d)
-        ops.gemm(dyr, Wt[0:d], None, Rows(dcat, M, 5 * d), d, d, EPI_BIAS)
+        ops.gemm(dyr, Wt[0:d], None, Rows.of(dO1.view(M, d)) if lean else Rows(dcat, M, 5 * d), d, d, EPI_BIAS)
         ops.gemm(dyr, Wt[d:5 * d], None, Rows(dbig[0, 3 * d:], M, 7 * d), 4 * d, d, EPI_DGELU, aux=save["hid_pre"],
                  ldaux=4 * d)
-        ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK,
-                     tr.dV, B, H, S, Sp, 5 * d, S * 5 * d, scale)
+        if lean:
+            ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], kept["O"], dO1, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK,
+                         tr.dV, B, H, S, Sp, d, S * d, scale)
+        else:
+            ops.attn_bwd(w.Q, w.K, save["V"], save["Qt"], save["Kt"], w.cat, tr.dO, lse_b, tr.delta, tr.dOt, tr.dQ, tr.dK,
+                         tr.dV, B, H, S, Sp, 5 * d, S * 5 * d, scale)
         # qk norm / rope backward writes [dq|dk|dv] straight into columns 0..3d of the [M, 7d] staging matrix
         qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
         ops.qk_norm_rope_bwd(qkv_b, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
@@ -378,8 +394,10 @@ def _backward(model, w, tr, sv, dout):
             m, dm = mods[name], dmods[name]
             ops.gate_bwd(srows(tr.dX, name, d), save["y_ff"][sl[name]], m[:, 5 * d:6 * d], 6 * d, tr.dy[sl[name]],
                          dm[:, 5 * d:6 * d], B, rows, d)
-            _wgrad(model, tr, Rows.of(w.hid[sl[name]]), 4 * d, Rows.of(tr.dy[sl[name]]), d, f"{p}.{ffn}.net.2.weight",
-                   f"{p}.{ffn}.net.2.bias")
+            # (FF pre-activation kept: the recompute pass formed no activation; gelu(hid_pre) is applied inside the transpose)
+            a_op = [(Rows.of(kept["hid_pre"][sl[name]]), 4 * d, True)] if kept is not None and "hid_pre" in kept \
+                else Rows.of(w.hid[sl[name]])
+            _wgrad(model, tr, a_op, 4 * d, Rows.of(tr.dy[sl[name]]), d, f"{p}.{ffn}.net.2.weight", f"{p}.{ffn}.net.2.bias")
         _dgrad_pair(model, tr, Rows.of(tr.dy[sl["txt"]]), f"{p}.ff_context.net.2.weight", Rows.of(dh_all[sl["txt"]]),
                     Rows.of(tr.dy[sl["img"]]), f"{p}.ff.net.2.weight", Rows.of(dh_all[sl["img"]]), d, 4 * d, epi=EPI_DGELU,
                     aux1=save["hid_pre"][sl["txt"]], aux2=save["hid_pre"][sl["img"]], ldaux=4 * d)

@@ -114,8 +114,13 @@ def scratch(name, numel, dtype, device):
     return t[:numel]
 
 
-def transpose(inp: Rows, N, out, ld_out, colsum_out=None, colsum_beta=1.0):
-    """out[N, ld_out] = inp[M, N]^T (zero padded); optional colsum_out[n] = beta*colsum_out[n] + sum_m inp[m,n]."""
+def transpose(inp: Rows, N, out, ld_out, colsum_out=None, colsum_beta=1.0, gelu=False):
+    """out[N, ld_out] = inp[M, N]^T (zero padded); optional colsum_out[n] = beta*colsum_out[n] + sum_m inp[m,n].
+    `gelu`: out = gelu_tanh(inp)^T (plain matrix, no column sums): the activation of a kept FF pre-activation."""
+    if gelu:
+        assert colsum_out is None and inp.rpb >= inp.M
+        check(lib().mgx_transpose_gelu_bf16(ptr(inp.t), ptr(out), inp.M, N, inp.ld, ld_out, stream()))
+        return
     part = None
     if colsum_out is not None:
         part = scratch("colsum_partial", lib().mgx_transpose_partial_elems(inp.M, N), F32, out.device)

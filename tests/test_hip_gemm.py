@@ -413,3 +413,25 @@ def test_gemm_pair_equals_two_launches(epi, B, L, Nimg, N, K, swap_w):
                 au = aux0[:B * L] if which == 0 else aux0[B * L:]
                 ref, amp = y * _dgelu(au.float().cpu()).cuda(), 1.2
         _close_bf16(out, ref.bfloat16(), y, amp)
+
+
+@pytest.mark.parametrize("M,N", [(4608, 12288), (1000, 256), (64 * 3 + 8, 136)])
+def test_transpose_with_gelu_equals_gelu_then_transpose(M, N):
+    """`mgx_transpose_gelu_bf16` (the weight-gradient operand of ff.net.2 / proj_out formed from a KEPT pre-activation) must be
+    bit for bit the transpose of what `mgx_gelu_bf16` writes -- which tests above hold to the GEMM epilogue's activation."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(M + N)
+    x = (3 * torch.randn(M, N, generator=g)).bfloat16().cuda()
+    Mp = (M + 63) // 64 * 64
+    y = torch.empty_like(x)
+    ops.gelu_rows(x, N, y, N, M, N)
+    want = torch.zeros(N, Mp, dtype=torch.bfloat16, device="cuda")
+    ops.transpose(Rows.of(y), N, want, Mp)
+    got = torch.full((N, Mp), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.transpose(Rows.of(x), N, got, Mp, gelu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = torch.nn.functional.gelu(x.float(), approximate="tanh")
+    assert ((got[:, :M].t().float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+    assert (got[:, M:] == 0).all()
