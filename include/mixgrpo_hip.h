@@ -200,17 +200,35 @@ int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t* x, long l
 int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
                          const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
                          uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream);
+/* ..._qs: Q (and Qt) leave as bf16(q * q_scale) -- one rounding, of the scaled value.  With q_scale = softmax scale * log2(e)
+ * the scores Q K^T are exponents of two: what mgx_attn_fwd_log2 consumes; every other consumer of that Q takes `scale` = ln 2
+ * (mgx_attn_bwd, mgx_attn_fwd_fp8), and mgx_qk_norm_rope_bwd_qs multiplies the incoming dQ by the same q_scale. */
+int mgx_qk_norm_rope_fwd_qs(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                            const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
+                            uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, float q_scale,
+                            void* stream);
 long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch);
 int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
                          const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dqkv,
                          long ld_dqkv /* elements between rows of dqkv, >= ld */, float* gwq, float* gwk, float* ws, int B,
                          int H, int S, int Sp, int rows_per_batch, int s0, void* stream);
 
+int mgx_qk_norm_rope_bwd_qs(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                            const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV, uint16_t* dqkv,
+                            long ld_dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S, int Sp,
+                            int rows_per_batch, int s0, float q_scale, void* stream);
+
 /* O = softmax(scale * Q K^T) V, non-causal, head_dim 128 (F.scaled_dot_product_attention under autocast):
  * Q,K [B,H,S,128], Vt [B,H,128,Sp] (Sp = S rounded up to 64, padding finite), O [B,S,ldo] at column h*128,
  * lse [B,H,S] (optional, natural log) for the backward pass. */
 int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H, int S,
                  int Sp, long ldo, long o_bstride, float scale, void* stream);
+
+/* The same with Q2 = Q * scale * log2(e) (mgx_qk_norm_rope_fwd_qs): P = 2^(Q2 K^T - m), lse still the natural logarithm.
+ * On the 64-query kernel (S % 256 == 0) the running maximum is subtracted by the matrix pipe -- a score tile's accumulator
+ * starts at -m -- and the per-score multiply-add of the softmax is gone (csrc/gen/attn_fwd64.py, ACC). */
+int mgx_attn_fwd_log2(const uint16_t* Q2, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H,
+                      int S, int Sp, long ldo, long o_bstride, void* stream);
 
 /* fp8 (OCP e4m3) variant of mgx_attn_fwd: the "fp8 MFMA attention path" of BASELINE.json configs[4].  The reference
  * has no fp8 attention; the entry points serve the same SDPA call sites (fastvideo/utils/sampling_utils.py:68-82,

@@ -65,9 +65,12 @@ SIGNATURES = {
     "mgx_ln_modulate_bwd_workspace": (_L, [_L, _L, _I]),
     "mgx_ln_modulate_bwd": (_I, [_P, _L, _P, _L, _L, _L, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P, _L, _I, _P]),
     "mgx_qk_norm_rope_fwd": (_I, [_P, _L] + [_P] * 10 + [_I] * 6 + [_P]),
+    "mgx_qk_norm_rope_fwd_qs": (_I, [_P, _L] + [_P] * 10 + [_I] * 6 + [_F, _P]),
     "mgx_qk_norm_rope_bwd_workspace": (_L, [_I, _I, _I]),
     "mgx_qk_norm_rope_bwd": (_I, [_P, _L] + [_P] * 8 + [_L] + [_P] * 3 + [_I] * 6 + [_P]),
+    "mgx_qk_norm_rope_bwd_qs": (_I, [_P, _L] + [_P] * 8 + [_L] + [_P] * 3 + [_I] * 6 + [_F, _P]),
     "mgx_attn_fwd": (_I, [_P] * 5 + [_I] * 4 + [_L, _L, _F, _P]),
+    "mgx_attn_fwd_log2": (_I, [_P] * 5 + [_I] * 4 + [_L, _L, _P]),
     "mgx_attn_fp8_quantize": (_I, [_P] * 7 + [_I] * 4 + [_P]),
     "mgx_attn_fwd_fp8": (_I, [_P] * 6 + [_I] * 4 + [_L, _L, _F, _P]),
     "mgx_attn_bwd": (_I, [_P] * 13 + [_I] * 4 + [_L, _L, _F, _P]),

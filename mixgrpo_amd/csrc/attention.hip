@@ -338,8 +338,23 @@ __global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnArgs g) {
 // all 512 registers, K / V^T tiles by LDS-DMA.  The body is a generated, hand-placed instruction stream: design, register
 // map and schedule in csrc/gen/attn_fwd64.py; checked on the CPU by tests/asm_emu.py (interpreter + hazard pass) before it
 // runs here.  Needs S % 256 == 0 (FLUX: 512 + 4096 tokens); other shapes take attn_fwd_kernel above.
+// ACC (attn_fwd64q_body.inc, mgx_attn_fwd_log2): Q arrives multiplied by scale * log2(e), the scores are exponents of two, and
+// from a block's second tile on the MFMA accumulator of a score tile starts at -m, so the softmax is v_exp_f32 straight from the
+// accumulator (no multiply-add per score: the loop is VALU-issue-bound, gen/attn_fwd64.py).
 #include "attn_fwd64_body.inc"
+#include "attn_fwd64q_body.inc"
 
+#define ATTN_FWD64_OPERANDS \
+  [tid] "v"(threadIdx.x), [q_lo] "s"((unsigned)qp), [q_hi] "s"((unsigned)(qp >> 32)), [k_lo] "s"((unsigned)kp), \
+                 [k_hi] "s"((unsigned)(kp >> 32)), [v_lo] "s"((unsigned)vp), [v_hi] "s"((unsigned)(vp >> 32)), \
+                 [o_lo] "s"((unsigned)op), [o_hi] "s"((unsigned)(op >> 32)), [l_lo] "s"((unsigned)lp), \
+                 [l_hi] "s"((unsigned)(lp >> 32)), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e), \
+                 [nloop] "s"((ntiles - 2) >> 1), [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128), \
+                 [nblk] "s"(count), [qt0] "s"(qt), [hh0] "s"(hh), [b0] "s"(b), [nq] "s"(nq), [nh] "s"(g.H), [kstep] "s"(g.S * 256), \
+                 [ostep] "s"(ostep), [obs] "s"((int)(g.o_bstride * 2)), [ob_lo] "s"((unsigned)ob), [ob_hi] "s"((unsigned)(ob >> 32)), \
+                 [sq] "s"(stride % nq), [dbh] "s"(stride / nq), [qstride] "s"(stride * 65536), [lstride] "s"(stride * 1024)
+
+template <bool ACC>
 __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(AttnArgs g) {
   // Persistent: the blocks (batch, head, q-tile) are cut into 8 contiguous ranges, one per XCD (blockIdx & 7 under round-robin
   // dispatch: speed only); workgroup j of an XCD takes blocks lo + j, lo + j + stride, ...  (stride = workgroups per XCD), so the
@@ -372,23 +387,14 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(AttnArgs g) {
   const unsigned long long lp = g.lse ? (unsigned long long)(g.lse + (long)bh * g.S + qt * 256) : 0ull;
   const int ntiles = g.S >> 6;
   const int ostep = (int)(g.ldo * 512);                       // bytes of 256 rows of O
-  asm volatile(ATTN_FWD64_BODY
-               :
-               : [tid] "v"(threadIdx.x), [q_lo] "s"((unsigned)qp), [q_hi] "s"((unsigned)(qp >> 32)), [k_lo] "s"((unsigned)kp),
-                 [k_hi] "s"((unsigned)(kp >> 32)), [v_lo] "s"((unsigned)vp), [v_hi] "s"((unsigned)(vp >> 32)),
-                 [o_lo] "s"((unsigned)op), [o_hi] "s"((unsigned)(op >> 32)), [l_lo] "s"((unsigned)lp),
-                 [l_hi] "s"((unsigned)(lp >> 32)), [sp2] "s"(g.Sp * 2), [ldo2] "s"((int)(g.ldo * 2)), [cs] "s"(g.scale_log2e),
-                 [nloop] "s"((ntiles - 2) >> 1), [kmax] "s"((ntiles - 1) * 16384), [vmax] "s"((ntiles - 1) * 128),
-                 [nblk] "s"(count), [qt0] "s"(qt), [hh0] "s"(hh), [b0] "s"(b), [nq] "s"(nq), [nh] "s"(g.H), [kstep] "s"(g.S * 256),
-                 [ostep] "s"(ostep), [obs] "s"((int)(g.o_bstride * 2)), [ob_lo] "s"((unsigned)ob), [ob_hi] "s"((unsigned)(ob >> 32)),
-                 [sq] "s"(stride % nq), [dbh] "s"(stride / nq), [qstride] "s"(stride * 65536), [lstride] "s"(stride * 1024)
-               : ATTN_FWD64_CLOBBERS);
+  if constexpr (ACC) asm volatile(ATTN_FWD64Q_BODY : : ATTN_FWD64_OPERANDS : ATTN_FWD64Q_CLOBBERS);
+  else asm volatile(ATTN_FWD64_BODY : : ATTN_FWD64_OPERANDS : ATTN_FWD64_CLOBBERS);
 }
 
 }  // namespace
 
-extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
-                            int H, int S, int Sp, long ldo, long o_bstride, float scale, void* stream) {
+static int attn_fwd_any(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B, int H, int S,
+                        int Sp, long ldo, long o_bstride, float scale_log2e, bool log2_scores, void* stream) {
   MGX_REQUIRE(Q && K && Vt && O, "null operand");
   MGX_REQUIRE(B > 0 && H > 0 && S > 0, "empty attention");
   MGX_REQUIRE(Sp >= S && Sp % 64 == 0, "Sp must be S rounded up to a multiple of 64");
@@ -396,7 +402,7 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   AttnArgs g;
   g.Q = Q; g.K = K; g.Vt = Vt; g.O = O; g.lse = lse;
   g.B = B; g.H = H; g.S = S; g.Sp = Sp; g.ldo = ldo; g.o_bstride = o_bstride;
-  g.scale_log2e = scale * 1.4426950408889634f;
+  g.scale_log2e = scale_log2e;
   static const int nw = getenv("MGX_ATTN_NW") ? atoi(getenv("MGX_ATTN_NW")) : 8;
   static const int defer = getenv("MGX_ATTN_DEFER") ? atoi(getenv("MGX_ATTN_DEFER")) : 1;
   const int lds = 2 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -415,10 +421,12 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
       (long)S * 256 < (1L << 31)) {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       attr = true;
     }
-    attn_fwd64_kernel<<<grid64, 256, 65536, st>>>(g);
+    if (log2_scores) attn_fwd64_kernel<true><<<grid64, 256, 65536, st>>>(g);
+    else attn_fwd64_kernel<false><<<grid64, 256, 65536, st>>>(g);
     MGX_CHECK_LAUNCH();
     return MGX_OK;
   }
@@ -429,4 +437,14 @@ extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t
   else attn_fwd_kernel<4, false><<<cdiv(S, 128) * H * B, 256, lds, st>>>(g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
+}
+
+extern "C" int mgx_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
+                            int H, int S, int Sp, long ldo, long o_bstride, float scale, void* stream) {
+  return attn_fwd_any(Q, K, Vt, O, lse, B, H, S, Sp, ldo, o_bstride, scale * 1.4426950408889634f, false, stream);
+}
+
+extern "C" int mgx_attn_fwd_log2(const uint16_t* Q2, const uint16_t* K, const uint16_t* Vt, uint16_t* O, float* lse, int B,
+                                 int H, int S, int Sp, long ldo, long o_bstride, void* stream) {
+  return attn_fwd_any(Q2, K, Vt, O, lse, B, H, S, Sp, ldo, o_bstride, 1.0f, true, stream);
 }

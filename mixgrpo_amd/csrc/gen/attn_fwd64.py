@@ -32,7 +32,16 @@ its own forced test (tests/test_hip_mmdit.py::test_attention_fwd64_rescale_path)
 The stream is checked on the CPU before it ever runs: tests/asm_emu.py interprets it (4 waves, LDS, waitcnt-visible data)
 against the oracle and a static pass checks the gfx950 software hazards (MFMA result -> VALU read 12 wait states, ...).
 
-Run `python mixgrpo_amd/csrc/gen/attn_fwd64.py` to rewrite mixgrpo_amd/csrc/attn_fwd64_body.inc (build.py does).
+Second variant (round 4, `ACC`, attn_fwd64q_body.inc, kernel attn_fwd64q_kernel): for a Q that the producer has ALREADY scaled by
+c (mgx_qk_norm_rope_fwd's q_scale: one bf16 rounding of q c instead of one of q), with m SUBTRACTED BY THE MATRIX PIPE: from
+the second tile on, the first of a score tile's eight MFMAs takes C = a block of 16 registers holding -m (one block per chain,
+written once when the first tile's maximum is known, moved by the fix-up), so the accumulator comes out as s c - m c and the
+softmax's `v_fma_f32 t, s, c, -mc` -- one of the ~3.5 single-issue instructions per MFMA gap in a loop that is issue-bound
+at 2552 cycles per iteration against the pipe's 2048 -- disappears: v_exp_f32 reads the accumulator directly.  The first tile
+(scores needed before m exists) still subtracts, with v_sub_f32.
+
+Run `python mixgrpo_amd/csrc/gen/attn_fwd64.py` to rewrite mixgrpo_amd/csrc/attn_fwd64_body.inc and attn_fwd64q_body.inc
+(build.py does).
 """
 import os
 import sys
@@ -58,6 +67,9 @@ QOFF_A, QOFF_B = 232, 233
 OOFF_A, OOFF_B = 234, 235
 LOFF = 236
 V_LAST = 239
+NM_A, NM_B = 240, X + 16  # ACC variant: v[240:255] / v[216:231] = 16 x (-m) of chain A / B, the SrcC of a score tile's first MFMA
+                          # (X + 16 .. X + 31 is otherwise only the epilogue's staging: dead while the blocks are live)
+ACC = False               # set by generate(acc=True)
 DBG_OFF, DBG_LO = 237, 238   # v237, v[238:239]: diagnostic builds only
 
 # scalars (copied from the asm operands into fixed registers, all clobbered)
@@ -104,12 +116,12 @@ def sr(i, n):
 
 
 class Chain:
-    def __init__(self, name, O, Q, S, P, M, MC, L):
-        self.name, self.O, self.Q, self.S, self.P, self.M, self.MC, self.L = name, O, Q, S, P, M, MC, L
+    def __init__(self, name, O, Q, S, P, M, MC, L, NM):
+        self.name, self.O, self.Q, self.S, self.P, self.M, self.MC, self.L, self.NM = name, O, Q, S, P, M, MC, L, NM
 
 
-CA = Chain("A", O_A, Q_A, S_A, P_A, M_A, MC_A, L_A)
-CB = Chain("B", O_B, Q_B, S_B, P_B, M_B, MC_B, L_B)
+CA = Chain("A", O_A, Q_A, S_A, P_A, M_A, MC_A, L_A, NM_A)
+CB = Chain("B", O_B, Q_B, S_B, P_B, M_B, MC_B, L_B, NM_B)
 
 
 class Asm:
@@ -145,11 +157,13 @@ def mfma_pv(ch, n):
     return f"{MFMA} {o}, {vr(VF + 4 * n, 4)}, {vr(ch.P + 4 * sidx, 4)}, {o}"
 
 
-def mfma_qk(ch, n):
-    """n = 8 kb + ks: S[kb] (+)= K fragment (kb, ks) x Q[ks]."""
+def mfma_qk(ch, n, first_tile=False):
+    """n = 8 kb + ks: S[kb] (+)= K fragment (kb, ks) x Q[ks].  ACC: a tile's first product starts from -m (the chain's NM
+    block) instead of 0 -- except in the block's first tile, whose scores define m."""
     kb, ks = n >> 3, n & 7
     sreg = vr(ch.S + 16 * kb, 16)
-    return f"{MFMA} {sreg}, {ar(KF + 4 * n, 4)}, {ar(ch.Q + 4 * ks, 4)}, {'0' if ks == 0 else sreg}"
+    c0 = vr(ch.NM, 16) if (ACC and not first_tile) else "0"
+    return f"{MFMA} {sreg}, {ar(KF + 4 * n, 4)}, {ar(ch.Q + 4 * ks, 4)}, {c0 if ks == 0 else sreg}"
 
 
 def ds_read_k(n, slot):
@@ -232,18 +246,23 @@ def block_advance_stores(A):
     A.e(f"s_sub_u32 {s(sLEFT)}, {s(sLEFT)}, 1")
 
 
-def softmax_gaps(ch, ngaps=32):
+def softmax_gaps(ch, ngaps=32, first_tile=False):
     """VALU stream of one chain's tile softmax, as `ngaps` lists (one per MFMA gap) + a tail list.
 
     Element e (0..31) = S register e; fma(e) two gaps before exp(e), the sum one gap after, cvt_pk(k) one gap after the
-    exponential of its odd element; temporaries rotate through T[e % 8]."""
+    exponential of its odd element; temporaries rotate through T[e % 8].  ACC: the accumulator already holds s c - m c (no
+    fma at all; the exponential reads it directly), except in the block's first tile: v_sub_f32 with m."""
     def t(e):
         return v(T + (e & 7))
 
     def fma(e):
+        if ACC:
+            return f"v_sub_f32 {t(e)}, {v(ch.S + e)}, {v(ch.MC)}" if first_tile else None
         return f"v_fma_f32 {t(e)}, {v(ch.S + e)}, {s(sCS)}, -{v(ch.MC)}"
 
     def exp(e):
+        if ACC and not first_tile:
+            return f"v_exp_f32 {t(e)}, {v(ch.S + e)}"
         return f"v_exp_f32 {t(e)}, {t(e)}"
 
     def add(e):
@@ -257,11 +276,11 @@ def softmax_gaps(ch, ngaps=32):
         return f"v_cvt_pk_bf16_f32 {v(ch.P + k)}, {t(2 * k)}, {t(2 * k + 1)}"
 
     gaps = [[] for _ in range(32)]
-    gaps[0] += [fma(0), fma(1), fma(2), fma(3), exp(0), exp(1)]
+    gaps[0] += [x for x in (fma(0), fma(1), fma(2), fma(3)) if x] + [exp(0), exp(1)]
     for g in range(1, 32):
         if g + 1 < 32:
             gaps[g].append(exp(g + 1))
-        if g + 3 < 32:
+        if g + 3 < 32 and fma(g + 3):
             gaps[g].append(fma(g + 3))
         if g == 1:
             gaps[g].append(add(1))          # e = 0 has no instruction of its own (pair sum)
@@ -284,7 +303,10 @@ def max_prefix(ch):
     for e in range(2, 32, 2):
         out.append(f"v_max3_f32 {t0}, {t0}, {v(ch.S + e)}, {v(ch.S + e + 1)}")
     out += [f"v_mov_b32 {t1}, {t0}", "s_nop 1", f"v_permlane32_swap_b32 {t0}, {t1}",
-            f"v_max_f32 {v(ch.M)}, {t0}, {t1}", f"v_mul_f32 {v(ch.MC)}, {v(ch.M)}, {s(sCS)}"]
+            f"v_max_f32 {v(ch.M)}, {t0}, {t1}",
+            f"v_mov_b32 {v(ch.MC)}, {v(ch.M)}" if ACC else f"v_mul_f32 {v(ch.MC)}, {v(ch.M)}, {s(sCS)}"]
+    if ACC:                                  # (scores are exponents already: mc == m) the SrcC block of every later score tile
+        out += [f"v_sub_f32 {v(ch.NM + j)}, 0, {v(ch.M)}" for j in range(16)]
     return out
 
 
@@ -294,6 +316,8 @@ def fixup(A, ch, back):
     t0, t1, al = v(X), v(X + 1), v(X + 2)
     A.e("s_nop 7")
     A.e("s_nop 7")                                          # every MFMA that wrote O / S of this chain has retired
+    if ACC:
+        return fixup_acc(A, ch, back)
     A.e(f"v_max_f32 {t0}, {v(ch.S)}, {v(ch.S + 1)}")
     for e in range(2, 32, 2):
         A.e(f"v_max3_f32 {t0}, {t0}, {v(ch.S + e)}, {v(ch.S + e + 1)}")
@@ -328,6 +352,48 @@ def fixup(A, ch, back):
             A.e(f"v_add_f32 {v(PS0)}, {v(PS0)}, {tb}")
         A.e(f"v_cvt_pk_bf16_f32 {v(ch.P + k)}, {ta}, {tb}")
     A.e("s_nop 7")                                          # accvgpr / P writes -> the next MFMAs
+    A.e(f"s_branch {back}")
+
+
+def fixup_acc(A, ch, back):
+    """ACC variant: the S registers hold s - m already, so r = max(0, row maximum of S) is how far m moves: alpha = 2^-r,
+    P = 2^(S - r), m += r, the -m block -= r (the chain's next score tile is issued after this returns)."""
+    t0, t1, al = v(X), v(X + 1), v(X + 2)
+    A.e(f"v_max_f32 {t0}, {v(ch.S)}, {v(ch.S + 1)}")
+    for e in range(2, 32, 2):
+        A.e(f"v_max3_f32 {t0}, {t0}, {v(ch.S + e)}, {v(ch.S + e + 1)}")
+    A.e(f"v_mov_b32 {t1}, {t0}")
+    A.e("s_nop 1")
+    A.e(f"v_permlane32_swap_b32 {t0}, {t1}")
+    A.e(f"v_max3_f32 {t0}, {t0}, {t1}, 0")                  # r
+    A.e(f"v_sub_f32 {t1}, 0, {t0}")
+    A.e(f"v_exp_f32 {al}, {t1}")                            # alpha = 2^-r
+    A.e(f"v_add_f32 {v(ch.M)}, {v(ch.M)}, {t0}")
+    A.e(f"v_mov_b32 {v(ch.MC)}, {v(ch.M)}")
+    for j in range(16):
+        A.e(f"v_sub_f32 {v(ch.NM + j)}, 0, {v(ch.M)}")
+    A.e(f"v_mul_f32 {v(ch.L)}, {v(ch.L)}, {al}")
+    for blk in range(0, 64, 8):
+        for j in range(8):
+            A.e(f"v_accvgpr_read_b32 {v(X + 8 + j)}, {a(ch.O + blk + j)}")
+        for j in range(8):
+            A.e(f"v_mul_f32 {v(X + 8 + j)}, {v(X + 8 + j)}, {al}")
+        for j in range(8):
+            A.e(f"v_accvgpr_write_b32 {a(ch.O + blk + j)}, {v(X + 8 + j)}")
+    for k in range(16):                                     # P and row sums again, at the new maximum
+        ta, tb = v(X + 8), v(X + 9)
+        A.e(f"v_sub_f32 {ta}, {v(ch.S + 2 * k)}, {t0}")
+        A.e(f"v_sub_f32 {tb}, {v(ch.S + 2 * k + 1)}, {t0}")
+        A.e(f"v_exp_f32 {ta}, {ta}")
+        A.e(f"v_exp_f32 {tb}, {tb}")
+        A.e("s_nop 0")
+        if k == 0:
+            A.e(f"v_add_f32 {v(PS0)}, {ta}, {tb}")
+        else:
+            A.e(f"v_add_f32 {v(PS0)}, {v(PS0)}, {ta}")
+            A.e(f"v_add_f32 {v(PS0)}, {v(PS0)}, {tb}")
+        A.e(f"v_cvt_pk_bf16_f32 {v(ch.P + k)}, {ta}, {tb}")
+    A.e("s_nop 7")                                          # accvgpr / P / -m writes -> the next MFMAs
     A.e(f"s_branch {back}")
 
 
@@ -374,9 +440,9 @@ def iteration(A, par, fixups, first=False, last=False):
     """One K/V tile i with i & 1 == par.  Slots: K(j), V(j) live in slot j & 1."""
     A.c(f"================ iteration parity {par}{' FIRST' if first else ''}{' LAST' if last else ''}")
     # ---------------- segment 1: MFMA chain B (P V of tile i-1, S^T of tile i), softmax chain A
-    mf = ([] if first else [mfma_pv(CB, n) for n in range(16)]) + [mfma_qk(CB, n) for n in range(16)]
+    mf = ([] if first else [mfma_pv(CB, n) for n in range(16)]) + [mfma_qk(CB, n, first_tile=first) for n in range(16)]
     ng = len(mf)
-    vg, vt = softmax_gaps(CA, ng)
+    vg, vt = softmax_gaps(CA, ng, first_tile=first)
     pre = []
     if first:
         pre = max_prefix(CA)
@@ -407,7 +473,7 @@ def iteration(A, par, fixups, first=False, last=False):
     end_of_softmax(A, CA, fixups, first)
     # ---------------- segment 2: MFMA chain A (P V of tile i, S^T of tile i+1), softmax chain B
     mf = [mfma_pv(CA, n) for n in range(16)] + ([] if last else [mfma_qk(CA, n) for n in range(16)])
-    vg, vt = softmax_gaps(CB, 32 if not last else 16)
+    vg, vt = softmax_gaps(CB, 32 if not last else 16, first_tile=first)
     pre = max_prefix(CB) if first else []
     lds, waits = {}, {0: "s_waitcnt lgkmcnt(0)"}            # every V^T fragment of the tile has landed
     if not last:
@@ -552,7 +618,7 @@ def block_start(A):
     A.e("s_waitcnt lgkmcnt(0)")
     A.e("s_barrier")                                 # every wave holds K(0): slot 0 may be refilled with K(2)
     for n in range(16):
-        A.e(mfma_qk(CA, n))
+        A.e(mfma_qk(CA, n, first_tile=True))
     A.e("s_nop 7")
     A.e("s_nop 7")
 
@@ -611,7 +677,16 @@ def stamp(A, k):
     A.e("s_mov_b64 exec, -1")
 
 
-def generate(diag=False):
+def generate(diag=False, acc=False):
+    global ACC
+    ACC = acc
+    try:
+        return _generate(diag)
+    finally:
+        ACC = False
+
+
+def _generate(diag):
     A = Asm()
     fixups = []
     if diag:
@@ -670,46 +745,49 @@ def generate(diag=False):
     return A.text()
 
 
-def clobbers():
-    regs = [f"v{i}" for i in range(4, V_LAST + 1)] + [f"a{i}" for i in range(256)] + \
+def clobbers(acc=False):
+    regs = [f"v{i}" for i in range(4, (255 if acc else V_LAST) + 1)] + [f"a{i}" for i in range(256)] + \
            [f"s{i}" for i in range(S_FIRST, S_LAST + 1)] + ["vcc", "scc", "memory"]
     return ", ".join(f'"{x}"' for x in regs)
 
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_BODY = os.path.join(HERE, "..", "attn_fwd64_body.inc")
+OUT_BODY_Q = os.path.join(HERE, "..", "attn_fwd64q_body.inc")
 
 
-def render(diag=False):
-    body = generate(diag)
+def render(diag=False, acc=False):
+    body = generate(diag, acc)
+    name = "ATTN_FWD64Q" if acc else "ATTN_FWD64"
     lines = ["// GENERATED by mixgrpo_amd/csrc/gen/attn_fwd64.py -- do not edit; see that file for the design.",
-             "#define ATTN_FWD64_CLOBBERS " + clobbers(),
-             "#define ATTN_FWD64_BODY \\"]
+             f"#define {name}_CLOBBERS " + clobbers(acc),
+             f"#define {name}_BODY \\"]
     for ln in body.rstrip("\n").split("\n"):
         lines.append('  "' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n" \\')
     lines.append('  ""')
     return "\n".join(lines) + "\n"
 
 
-def write(path=OUT_BODY):
-    txt = render()
-    old = open(path).read() if os.path.exists(path) else None
-    if old != txt:
-        with open(path, "w") as f:
-            f.write(txt)
-    return path
+def write():
+    for path, acc in ((OUT_BODY, False), (OUT_BODY_Q, True)):
+        txt = render(acc=acc)
+        old = open(path).read() if os.path.exists(path) else None
+        if old != txt:
+            with open(path, "w") as f:
+                f.write(txt)
+    return OUT_BODY, OUT_BODY_Q
 
 
 if __name__ == "__main__":
     if "--print" in sys.argv:
-        sys.stdout.write(generate("--diag" in sys.argv))
+        sys.stdout.write(generate("--diag" in sys.argv, "--acc" in sys.argv))
     elif "--diag" in sys.argv:                      # scratch/fwd64_diag.hip includes this one
         for a_ in sys.argv:
             if a_.startswith("--timing-only="):
                 TIMING_ONLY.update(a_.split("=")[1].split(","))
         out = os.path.join(HERE, "..", "..", "..", "scratch", "attn_fwd64_diag_body.inc")
         with open(out, "w") as f:
-            f.write(render(diag=True))
+            f.write(render(diag=True, acc="--acc" in sys.argv))
         print(out)
     else:
         print(write())

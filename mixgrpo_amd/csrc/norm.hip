@@ -245,6 +245,7 @@ struct QkArgs {
   int H, S, Sp;
   int rows_per_batch;  // tokens of this stream per sample
   int s0;              // position of the stream's first token in the joint sequence
+  float q_scale;       // Q (and Qt) leave as bf16(q * q_scale): 1, or softmax scale * log2(e) for mgx_attn_fwd_log2
 };
 
 template <bool EMIT_T>
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
   const int t0 = blockIdx.x * 64;
   const int HD = 128;
   const long dmodel = (long)a.H * HD;
-  const float wq0 = a.wq[2 * lane], wq1 = a.wq[2 * lane + 1];
+  const float wq0 = a.wq[2 * lane] * a.q_scale, wq1 = a.wq[2 * lane + 1] * a.q_scale;   // (x 1 is exact)
   const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
   // four tokens per pass, every load of the pass issued before the first use: a wave instruction of this kernel moves 256 bytes
   // (one head row), so the bytes a wave keeps in flight are what its dependent chain allows -- one token at a time (three
@@ -348,6 +349,7 @@ struct QkBwdArgs {
   long ldo;        // elements between consecutive rows of dqkv (>= 3*H*128: e.g. the [M, 7d] staging matrix of the single blocks)
   float* part;     // [nblocks][2][128]
   int H, S, Sp, rows_per_batch, s0;
+  float q_scale;   // dQ is the gradient of bf16(q * q_scale): it enters multiplied by q_scale
 };
 
 __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
@@ -395,7 +397,8 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
       for (int which = 0; which < 2; ++which) {
         const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
         const float x0 = bf2f(ux[u][which] & 0xffff), x1 = bf2f(ux[u][which] >> 16);
-        const float go0 = bf2f(ug[u][which] & 0xffff), go1 = bf2f(ug[u][which] >> 16);
+        const float gs = which ? 1.f : a.q_scale;
+        const float go0 = bf2f(ug[u][which] & 0xffff) * gs, go1 = bf2f(ug[u][which] >> 16) * gs;
         // rope^T: out0 = y0 c0 - y1 s0 ; out1 = y1 c1 + y0 s1
         const float gy0 = go0 * c0 + go1 * s1;
         const float gy1 = -go0 * s0 + go1 * c1;
@@ -502,14 +505,16 @@ extern "C" int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t
   return MGX_OK;
 }
 
-extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                                    const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
-                                    uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream) {
+extern "C" int mgx_qk_norm_rope_fwd_qs(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                       const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
+                                       uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, float q_scale,
+                                       void* stream) {
   MGX_REQUIRE(qkv && wq && wk && cos && sin && Q && K && Vt, "null argument");
   MGX_REQUIRE((V != nullptr) == (Qt != nullptr) && (V != nullptr) == (Kt != nullptr), "V, Qt, Kt come together");
   MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Sp >= S, "bad sizes");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
-  QkArgs a{qkv, ld, wq, wk, cos, sin, Q, K, Vt, V, Qt, Kt, H, S, Sp, rows_per_batch, s0};
+  MGX_REQUIRE(q_scale > 0.f, "q_scale must be positive");
+  QkArgs a{qkv, ld, wq, wk, cos, sin, Q, K, Vt, V, Qt, Kt, H, S, Sp, rows_per_batch, s0, q_scale};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   if (V) qk_norm_rope_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else qk_norm_rope_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a);
@@ -517,19 +522,25 @@ extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* w
   return MGX_OK;
 }
 
+extern "C" int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                    const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
+                                    uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream) {
+  return mgx_qk_norm_rope_fwd_qs(qkv, ld, wq, wk, cos, sin, Q, K, Vt, V, Qt, Kt, B, H, S, Sp, rows_per_batch, s0, 1.0f, stream);
+}
+
 extern "C" long mgx_qk_norm_rope_bwd_workspace(int B, int H, int rows_per_batch) {
   return ((long)cdiv(rows_per_batch, 64) * H * B + QK_FIN_G) * 2 * 128;    // per-block partials + the first stage's sums
 }
 
-extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
-                                    const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
-                                    uint16_t* dqkv, long ld_dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S,
-                                    int Sp, int rows_per_batch, int s0, void* stream) {
+extern "C" int mgx_qk_norm_rope_bwd_qs(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                       const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
+                                       uint16_t* dqkv, long ld_dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S,
+                                       int Sp, int rows_per_batch, int s0, float q_scale, void* stream) {
   MGX_REQUIRE(qkv && wq && wk && cos && sin && dQ && dK && dV && dqkv && gwq && gwk && ws, "null argument");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
   MGX_REQUIRE(ld_dqkv >= ld && ld_dqkv % 2 == 0, "dqkv rows must hold [dq | dk | dv] and keep 4-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ld_dqkv, ws, H, S, Sp, rows_per_batch, s0};
+  QkBwdArgs a{qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ld_dqkv, ws, H, S, Sp, rows_per_batch, s0, q_scale};
   dim3 grid(cdiv(rows_per_batch, 64), H, B);
   qk_norm_rope_bwd_kernel<<<grid, 256, 0, st>>>(a);
   const long nblocks = (long)grid.x * grid.y * grid.z;
@@ -538,4 +549,12 @@ extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* w
   qk_bwd_finish_kernel<<<16, 256, 0, st>>>(mid, gwq, gwk, QK_FIN_G);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
+}
+
+extern "C" int mgx_qk_norm_rope_bwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
+                                    const float* sin, const uint16_t* dQ, const uint16_t* dK, const uint16_t* dV,
+                                    uint16_t* dqkv, long ld_dqkv, float* gwq, float* gwk, float* ws, int B, int H, int S,
+                                    int Sp, int rows_per_batch, int s0, void* stream) {
+  return mgx_qk_norm_rope_bwd_qs(qkv, ld, wq, wk, cos, sin, dQ, dK, dV, dqkv, ld_dqkv, gwq, gwk, ws, B, H, S, Sp, rows_per_batch,
+                                 s0, 1.0f, stream);
 }

@@ -357,14 +357,25 @@ class FluxTransformer2DModel(torch.nn.Module):
         """Joint attention of the current Q / K / Vt workspace into O (+ LSE).  `attention_dtype == "fp8"` (BASELINE.json
         configs[4]) quantises the operands per (batch, head) to e4m3 and runs both contractions on fp8 MFMA; every
         forward of the model (rollout, training forward) then uses it, the backward stays bf16."""
-        H, hd = self.cfg.num_attention_heads, self.cfg.attention_head_dim
-        scale = 1.0 / math.sqrt(hd)
+        H = self.cfg.num_attention_heads
+        scale = self.attn_scale()
         if self.attention_dtype == "fp8":
             q8, k8, v8t, amax = w.fp8_operands()
             ops.attn_fp8_quantize(w.Q, w.K, w.Vt, q8, k8, v8t, amax, w.B, H, w.S, w.Sp)
             ops.attn_fwd_fp8(q8, k8, v8t, amax, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
+        elif ops.Q_PRESCALE:
+            ops.attn_fwd_log2(w.Q, w.K, w.Vt, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride)
         else:
             ops.attn_fwd(w.Q, w.K, w.Vt, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
+
+    def q_scale(self):
+        """What `mgx_qk_norm_rope_fwd_qs` multiplies q by before its one bf16 rounding: softmax scale * log2(e) (the scores
+        are exponents of two: mgx_attn_fwd_log2), or 1 under MGX_ATTN_Q_PRESCALE=0."""
+        return ops.LOG2E / math.sqrt(self.cfg.attention_head_dim) if ops.Q_PRESCALE else 1.0
+
+    def attn_scale(self):
+        """The `scale` every other consumer of that Q takes (mgx_attn_bwd, mgx_attn_fwd_fp8): ln 2 for the prescaled Q."""
+        return ops.LN2 if ops.Q_PRESCALE else 1.0 / math.sqrt(self.cfg.attention_head_dim)
 
     def _rope(self, txt_ids, img_ids):
         key = (id(txt_ids), txt_ids._version, tuple(txt_ids.shape), id(img_ids), img_ids._version, tuple(img_ids.shape))
@@ -458,7 +469,7 @@ class FluxTransformer2DModel(torch.nn.Module):
                 fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv_buf[sl[name]]))), 3 * d, d)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             ops.qk_norm_rope(qkv_buf[sl[name]], self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
-                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0,
+                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale(),
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         # the attention output lives in the block's keep buffer when there is one (written here, read by the backward):
         # no copy between the workspace and the kept tensor
@@ -533,7 +544,7 @@ class FluxTransformer2DModel(torch.nn.Module):
                      Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
                      aux=save["hid_pre"] if save is not None else (keep["hid_pre"] if ff_kept else None))
         ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
-                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0,
+                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0, q_scale=self.q_scale(),
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward
             if not ff_kept:

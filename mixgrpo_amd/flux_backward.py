@@ -280,7 +280,7 @@ def _backward(model, w, tr, sv, dout):
     M = B * S
     dev = model.store.device
     st_, cos, sin = sv["st"], sv["cos"], sv["sin"]
-    scale = 1.0 / math.sqrt(cfg.attention_head_dim)
+    scale, q_scale = model.attn_scale(), model.q_scale()   # (ln 2, scale * log2 e) for the prescaled Q of mgx_attn_fwd_log2
     store = model.store
     g32 = store.ensure_grad()
     dst = torch.zeros(B, d, dtype=BF16, device=dev)        # grad wrt st = silu(temb), summed over all users
@@ -358,7 +358,7 @@ def _backward(model, w, tr, sv, dout):
         qkv_b = kept["qkv"] if kept is not None and "qkv" in kept else w.qkv
         ops.qk_norm_rope_bwd(qkv_b, model.W32(f"{p}.attn.norm_q.weight"), model.W32(f"{p}.attn.norm_k.weight"), cos, sin,
                              tr.dQ, tr.dK, tr.dV, dbig, store.view(g32, f"{p}.attn.norm_q.weight"),
-                             store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0, ld_dqkv=7 * d)
+                             store.view(g32, f"{p}.attn.norm_k.weight"), B, H, S, Sp, S, 0, ld_dqkv=7 * d, q_scale=q_scale)
         dbr = Rows.of(dbig)
         _wgrad(model, tr, Rows.of(save["nrm1"]), d, dbr, 7 * d, f"{p}.attn.to_q.weight", f"{p}.attn.to_q.bias", rows=True)
         _dgrad(model, tr, dbr, 7 * d, d, f"{p}.attn.to_q.weight", Rows.of(tr.dnrm), rows=True)
@@ -423,7 +423,7 @@ def _backward(model, w, tr, sv, dout):
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             ops.qk_norm_rope_bwd(qkv_b[sl[name]], model.W32(f"{p}.attn.{nq}.weight"), model.W32(f"{p}.attn.{nk}.weight"), cos,
                                  sin, tr.dQ, tr.dK, tr.dV, dqkv_all[sl[name]], store.view(g32, f"{p}.attn.{nq}.weight"),
-                                 store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0)
+                                 store.view(g32, f"{p}.attn.{nk}.weight"), B, H, S, Sp, rows, s0, q_scale=q_scale)
             _wgrad(model, tr, Rows.of(save["nrm1"][sl[name]]), d, Rows.of(dqkv_all[sl[name]]), 3 * d, f"{p}.attn.{qkvn[0]}.weight",
                    f"{p}.attn.{qkvn[0]}.bias", rows=True)
         _dgrad_pair(model, tr, Rows.of(dqkv_all[sl["txt"]]), f"{p}.attn.add_q_proj.weight", Rows.of(tr.dnrm[sl["txt"]]),

@@ -141,23 +141,37 @@ def ln_modulate_bwd(dy, x: Rows, scale, mod_ld, dx: Rows, accumulate, dshift, ds
                                     dscale.data_ptr(), ptr(ws), x.M, D, stream()))
 
 
-def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s0, V=None, Qt=None, Kt=None):
-    check(lib().mgx_qk_norm_rope_fwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K), ptr(Vt),
-                                     ptr(V), ptr(Qt), ptr(Kt), B, H, S, Sp, rows_per_batch, s0, stream()))
+LN2, LOG2E = 0.6931471805599453, 1.4426950408889634
+# Q leaves mgx_qk_norm_rope_fwd_qs multiplied by softmax scale * log2(e) (scores = exponents of two: mgx_attn_fwd_log2's
+# accumulator-initialised softmax); every other consumer of that Q takes scale = ln 2.  MGX_ATTN_Q_PRESCALE=0: plain Q.
+Q_PRESCALE = os.environ.get("MGX_ATTN_Q_PRESCALE", "1") != "0"
 
 
-def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0, ld_dqkv=None):
+def qk_norm_rope(qkv, wq, wk, cos, sin, Q, K, Vt, B, H, S, Sp, rows_per_batch, s0, V=None, Qt=None, Kt=None, q_scale=1.0):
+    check(lib().mgx_qk_norm_rope_fwd_qs(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K),
+                                        ptr(Vt), ptr(V), ptr(Qt), ptr(Kt), B, H, S, Sp, rows_per_batch, s0, float(q_scale),
+                                        stream()))
+
+
+def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S, Sp, rows_per_batch, s0, ld_dqkv=None,
+                     q_scale=1.0):
     """`dqkv`: a tensor whose data_ptr() is the first element of the [rows, >= 3d] output; `ld_dqkv` its row stride in
-    elements (default: 3d, a plain matrix)."""
+    elements (default: 3d, a plain matrix).  `q_scale`: the forward's (dQ is the gradient of the scaled Q)."""
     ws = scratch("qk_bwd", lib().mgx_qk_norm_rope_bwd_workspace(B, H, rows_per_batch), F32, qkv.device)
-    check(lib().mgx_qk_norm_rope_bwd(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
-                                     ptr(dV), dqkv.data_ptr(), qkv.shape[-1] if ld_dqkv is None else ld_dqkv, ptr(gwq),
-                                     ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0, stream()))
+    check(lib().mgx_qk_norm_rope_bwd_qs(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
+                                        ptr(dV), dqkv.data_ptr(), qkv.shape[-1] if ld_dqkv is None else ld_dqkv, ptr(gwq),
+                                        ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0, float(q_scale), stream()))
 
 
 def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):
     check(lib().mgx_attn_fwd(ptr(Q), ptr(K), ptr(Vt), O_ptr_tensor.data_ptr(), ptr(lse), B, H, S, Sp, ldo, o_bstride,
                              scale, stream()))
+
+
+def attn_fwd_log2(Q2, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride):
+    """Q2 = Q * scale * log2(e), from qk_norm_rope(..., q_scale=scale * LOG2E)."""
+    check(lib().mgx_attn_fwd_log2(ptr(Q2), ptr(K), ptr(Vt), O_ptr_tensor.data_ptr(), ptr(lse), B, H, S, Sp, ldo, o_bstride,
+                                  stream()))
 
 
 def attn_fp8_quantize(Q, K, Vt, Q8, K8, V8t, amax, B, H, S, Sp):

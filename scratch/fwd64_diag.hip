@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "attn_fwd64_diag_body.inc"
+#ifdef DIAG_ACC   // generator run with --acc: the macros carry the Q-variant's names
+#define ATTN_FWD64_BODY ATTN_FWD64Q_BODY
+#define ATTN_FWD64_CLOBBERS ATTN_FWD64Q_CLOBBERS
+#endif
 extern "C" __global__ void __launch_bounds__(256, 1)
 fwd64_diag_kernel(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, unsigned long long* dbg, int B, int H,
                   int S, long ldo, long o_bstride, float scale_log2e) {

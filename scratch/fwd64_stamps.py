@@ -2,16 +2,21 @@
 (prologue / first iteration / steady-state loop / last iteration / epilogue) and the clock the chip holds."""
 import ctypes as C, math, os, subprocess, sys, torch
 sys.path.insert(0, ".")
-variant = sys.argv[1] if len(sys.argv) > 1 else ""
-subprocess.check_call([sys.executable, "mixgrpo_amd/csrc/gen/attn_fwd64.py", "--diag"] + ([f"--timing-only={variant}"] if variant else []))
-print(f"==== variant: {variant or 'real kernel'}")
-so = f"scratch/libfwd64_diag_{variant.replace(',', '_') or 'real'}.so"
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Iscratch", "scratch/fwd64_diag.hip", "-o", so])
+variant = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else ""
+acc = len(sys.argv) > 2 and sys.argv[2] == "acc"          # the accumulator-initialised stream (attn_fwd64q) on a prescaled Q
+subprocess.check_call([sys.executable, "mixgrpo_amd/csrc/gen/attn_fwd64.py", "--diag"] + (["--acc"] if acc else []) +
+                      ([f"--timing-only={variant}"] if variant else []))
+print(f"==== variant: {variant or 'real kernel'}{' (attn_fwd64q)' if acc else ''}")
+so = f"scratch/libfwd64_diag_{variant.replace(',', '_') or 'real'}{'_acc' if acc else ''}.so"
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Iscratch"] + (["-DDIAG_ACC"] if acc else []) +
+                      ["scratch/fwd64_diag.hip", "-o", so])
 lib = C.CDLL(so)
 lib.fwd64_diag.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_long, C.c_long, C.c_float, C.c_void_p]
 B, H, S = 8, 24, 4608
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, S, 128, device="cuda").bfloat16() for _ in range(3))
+if acc:
+    q = (q.float() * (1.4426950408889634 / math.sqrt(128))).bfloat16()
 vt = v.transpose(-1, -2).contiguous()
 O = torch.empty(B, S, H * 128, device="cuda", dtype=torch.bfloat16)
 nwg = (S // 256) * H * B
