@@ -159,6 +159,17 @@ int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias,
                      uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                      long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
                      long sk_workspace_elems, void* stream);
+/* A Linear whose output leaves TRANSPOSED: Ct[b][f][t] = bf16(X[b * tok_rpb + t, :] . W[f, :] + bias[f]), ld_ct elements
+ * between feature rows, ct_bstride between token batches -- the V^T [B, H, 128, Sp] operand of mgx_attn_fwd* straight from
+ * the value projection (the nn.Linear to_v / add_v_proj of diffusers' FluxAttnProcessor2_0 followed by the transpose SDPA's
+ * kernels do internally; call sites fastvideo/utils/sampling_utils.py:68-82), mgx_qk_norm_rope_fwd* then called with Vt = NULL.
+ * Same persistent kernel with the operand roles swapped.  Returns 1 -- nothing launched -- for shapes that kernel cannot take
+ * (fewer than 128 output tiles of 256 x 256, tok_rpb % 64 != 0 with several batches, alignments below 16 bytes): the caller
+ * then keeps the plain projection + mgx_qk_norm_rope_fwd's transposing pass. */
+int mgx_linear_bf16_t(const uint16_t* X, const uint16_t* W, const uint16_t* bias, uint16_t* Ct, int tokens, int F, int K,
+                      long ldx, long ldw, long ld_ct, long tok_rpb, long ct_bstride, float* sk_workspace,
+                      long sk_workspace_elems, void* stream);
+
 /* TWO such problems with equal N, K, epilogue and leading dimensions in ONE launch of the persistent kernel: the text- and the
  * image-stream Linear of a FLUX double block, which diffusers issues as separate nn.Linear calls (to_q/k/v | add_q/k/v_proj,
  * to_out | to_add_out, ff | ff_context; call sites fastvideo/utils/sampling_utils.py:68-82, train_grpo_flux.py:134-144,600).
@@ -196,7 +207,8 @@ int mgx_ln_modulate_bwd(const uint16_t* dy, long lddy, const uint16_t* x, long l
  * split: qkv [B*rows_per_batch, 3*H*128] -> Q,K [B,H,S,128] (rounded once to bf16), Vt [B,H,128,Sp], written
  * at sequence positions s0 .. s0+rows_per_batch-1 of the joint sequence (diffusers FluxAttnProcessor2_0). */
 /* V, Qt, Kt (all or none): extra layouts the attention backward consumes -- V row-major [B,H,S,128] and
- * Q^T, K^T [B,H,128,Sp] (padding must be finite: allocate zeroed). */
+ * Q^T, K^T [B,H,128,Sp] (padding must be finite: allocate zeroed).  Vt = NULL (without the extras): the v columns are not
+ * read and V^T is not written (mgx_linear_bf16_t wrote it). */
 int mgx_qk_norm_rope_fwd(const uint16_t* qkv, long ld, const float* wq, const float* wk, const float* cos,
                          const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
                          uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, void* stream);

@@ -75,6 +75,12 @@ struct GemmArgs {
   const bf16_raw* bias2;
   const bf16_raw* gate2;
   bf16_raw* aux2;
+  // transposed-output Linear (mgx_linear_bf16_t; EPI_BIAS, persistent kernel, 16-byte epilogue only): the roles are swapped -- A =
+  // the weight rows (M = output features), W = the activations (N = tokens) -- so C[feature][token] comes out token-contiguous:
+  // V^T of the attention without a transposing pass.  bias_rows: bias[M] is indexed by the ROW; col_rpb > 0: column n lies in
+  // column batch n / col_rpb at C + (n / col_rpb) * col_bstride + row offset + n % col_rpb (col_rpb % 64 == 0).
+  int bias_rows;
+  long col_rpb, col_bstride;
 };
 
 // operands of the problem that tile row m0 belongs to (PAIR launches), as a GemmArgs the ordinary epilogue can take
@@ -567,7 +573,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
   const long mu = m0 + (wu >> 2) * 128, nu = n0 + (wu & 3) * 64;
   if (mu >= g.M || nu >= g.N) return;               // wave-uniform: nothing of this wave's block is inside the matrix
   const long bu = (uint32_t)mu / (uint32_t)g.c.rpb;
-  const char* cbase = reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + nu) * 2;
+  long ncol = nu;                                   // the wave's first column inside C's row (column batches: mgx_linear_bf16_t)
+  if (EPI == EPI_BIAS && g.col_rpb > 0) {
+    const uint32_t cbt = (uint32_t)nu / (uint32_t)g.col_rpb;
+    ncol = (long)cbt * g.col_bstride + (long)((uint32_t)nu - cbt * (uint32_t)g.col_rpb);
+  }
+  const char* cbase = reinterpret_cast<const char*>(g.C) + (bu * g.c.bstride + (mu - bu * g.c.rpb) * g.c.ld + ncol) * 2;
   const char* abase = reinterpret_cast<const char*>(g.aux) + (mu * g.ldaux + nu) * 2;
   const int rmax = (int)(g.M - 1 - mu < 127 ? g.M - 1 - mu : 127);      // last valid row of the block
   const int f0 = lane_feat(fq, 0), f1 = lane_feat(fq, 2);                // first feature of the lane's two 8-feature halves
@@ -577,7 +588,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
   auto rowclamp = [&](int j) { const int r = fr + 16 * j; return (uint32_t)(r < rmax ? r : rmax); };
 
   uint4 bias0 = make_uint4(0, 0, 0, 0), bias1 = bias0;
-  if (g.bias) {
+  const bool brows = EPI == EPI_BIAS && g.bias_rows && g.bias;      // wave-uniform
+  float brow[MT];
+  if (brows) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) brow[j] = bf2f(g.bias[mu + rowclamp(j)]);
+  } else if (g.bias) {
     const char* bb = reinterpret_cast<const char*>(g.bias) + nu * 2;
     bias0 = *reinterpret_cast<const uint4*>(bb + c0);
     bias1 = *reinterpret_cast<const uint4*>(bb + c1);
@@ -611,16 +627,30 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
     float bias[16];
     unpack8(bias0, bias);
     unpack8(bias1, bias + 8);
+    if (brows) {                                     // (a wave-uniform branch around the loop: no per-element select)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      float v[16];
+      for (int j = 0; j < MT; ++j) {
+        float v[16];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
-      y[j][0] = pack8(v);
-      y[j][1] = pack8(v + 8);
-      __builtin_amdgcn_sched_barrier(0);           // row by row: interleaving the rows doubles the live registers
+          for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + brow[j];
+        y[j][0] = pack8(v);
+        y[j][1] = pack8(v + 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
+        y[j][0] = pack8(v);
+        y[j][1] = pack8(v + 8);
+        __builtin_amdgcn_sched_barrier(0);           // row by row: interleaving the rows doubles the live registers
+      }
     }
   }
 #pragma unroll
@@ -1023,6 +1053,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
 #undef MMA
 }
 
+// what the persistent 256x256 kernel takes (the rest goes to gemm_kernel): enough tiles to fill most of the 256 CUs
+// (measured, scratch/bench_gemm_small.py: 168 tiles 843-935 vs 591-691 TFLOP/s, 120 tiles equal, 24-96 tiles slower)
+bool persistent_ok(const GemmArgs& g) {
+  const long tiles_big = (long)cdiv(g.M, 256) * cdiv(g.N, 256);
+  static const long min_tiles = getenv("MGX_GEMM_BIG_MIN_TILES") ? atol(getenv("MGX_GEMM_BIG_MIN_TILES")) : 128;
+  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;     // 0 (debugging): 128x128 kernel everywhere
+  const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= min_tiles && (g.N % 256 == 0 || g.N >= 2048);
+  return big && mode != 0 && g.span32 && g.K >= 2 * BK;
+}
+
 template <int EPI, bool CONV = false>
 int launch(const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
@@ -1031,11 +1071,7 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
     static const int band_env = getenv("MGX_GEMM_BAND") ? atoi(getenv("MGX_GEMM_BAND")) : 0;      // A/B only
     g.band = band_env > 0 ? min(band_env, tiles_m) : (tiles_n <= 16 ? 1 : (tiles_m <= 16 ? tiles_m : 4));
   }
-  // the 256x256 tile needs enough tiles to fill most of the 256 CUs; skinny / small problems keep the 128x128 tile
-  // (measured, scratch/bench_gemm_small.py: 168 tiles 843-935 vs 591-691 TFLOP/s, 120 tiles equal, 24-96 tiles slower)
   const long tiles_big = (long)cdiv(g.M, 256) * cdiv(g.N, 256);
-  static const long min_tiles = getenv("MGX_GEMM_BIG_MIN_TILES") ? atol(getenv("MGX_GEMM_BIG_MIN_TILES")) : 128;
-  const bool big = g.M >= 256 && g.N >= 256 && tiles_big >= min_tiles && (g.N % 256 == 0 || g.N >= 2048);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1048,9 +1084,7 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
     attr_set = true;
   }
   const bool pair = !CONV && g.m_split != 0;
-  // MGX_GEMM_MODE=0 (debugging) forces the 128x128 kernel everywhere
-  static const int mode = getenv("MGX_GEMM_MODE") ? atoi(getenv("MGX_GEMM_MODE")) : 9;
-  if (big && mode != 0 && g.span32 && g.K >= 2 * BK) {
+  if (persistent_ok(g)) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     // stream-K tail (caller gave a workspace): allowed when it shortens the launch.  A tile's K-loop takes T ~ K * 0.0247 us
     // (2 * 256 * 256 * K FLOP at the 5.3 TFLOP/s a CU sustains in this kernel).  Unsplit, the last round takes T; split P ways
@@ -1235,6 +1269,40 @@ extern "C" int mgx_gemm_bf16_pair(const uint16_t* A1, const uint16_t* W1, const 
                           epilogue, beta, sk_workspace, sk_workspace_elems, stream);
 }
 
+// Ct[b][f][t] = bf16(X[b * tok_rpb + t, :] . W[f, :] + bias[f]): a Linear whose output leaves TRANSPOSED, token-contiguous
+// (ld_ct elements between feature rows, ct_bstride between token batches) -- the V^T [B, H, 128, Sp] operand of the attention
+// kernels straight from the projection, without the transposing pass of mgx_qk_norm_rope_fwd.  Runs the persistent kernel
+// with the operand roles swapped (rows = features, columns = tokens; GemmArgs::bias_rows / col_rpb).  Returns 1 -- nothing
+// launched -- for what that kernel or its 16-byte epilogue cannot take (few tiles, odd alignments): the caller then keeps the
+// plain Linear + transposing pass.
+extern "C" int mgx_linear_bf16_t(const uint16_t* X, const uint16_t* W, const uint16_t* bias, uint16_t* Ct, int tokens, int F, int K,
+                                 long ldx, long ldw, long ld_ct, long tok_rpb, long ct_bstride, float* sk_workspace,
+                                 long sk_workspace_elems, void* stream) {
+  MGX_REQUIRE(X && W && Ct && tokens > 0 && F > 0 && K > 0 && tok_rpb > 0, "bad argument");
+  MGX_REQUIRE(!sk_workspace || (sk_workspace_elems >= mgx_gemm_sk_workspace_elems() && (uintptr_t)sk_workspace % 16 == 0),
+              "stream-K workspace too small (mgx_gemm_sk_workspace_elems) or misaligned");
+  const long rpb = tok_rpb < tokens ? tok_rpb : tokens;
+  const long nb = (tokens + rpb - 1) / rpb;
+  const bool ok = K % BK == 0 && tokens % 8 == 0 && F % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ld_ct % 8 == 0 && ct_bstride % 8 == 0 &&
+                  (nb == 1 || rpb % 64 == 0) && ld_ct >= rpb && ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0) &&
+                  ((uintptr_t)Ct % 16 == 0) && (!bias || (uintptr_t)bias % 2 == 0);
+  if (!ok) return 1;
+  GemmArgs g{};
+  g.A = W; g.W = X; g.bias = bias; g.C = Ct;
+  g.M = F; g.N = tokens; g.K = K;
+  g.a = RowMap{ldw, 1L << 30, 0};
+  g.c = RowMap{ld_ct, 1L << 30, 0};
+  g.ldw = ldx;
+  g.conv_shift = -1;
+  g.sk_ws = sk_workspace;
+  g.rowwise_ok = 1;
+  g.bias_rows = 1;
+  g.col_rpb = nb > 1 ? rpb : 0; g.col_bstride = ct_bstride;
+  g.span32 = ((long)F * ldw) * 2 < (1L << 32) && ((long)tokens * ldx) * 2 < (1L << 32);
+  if (!persistent_ok(g)) return 1;
+  return launch<EPI_BIAS>(g, (hipStream_t)stream);
+}
+
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,
                              uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                              long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, void* stream) {
@@ -1256,7 +1324,7 @@ extern "C" int mgx_conv3x3_nhwc(const uint16_t* x, const uint16_t* Wt, const uin
   MGX_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)Wt % 16 == 0) && ((uintptr_t)out % 8 == 0), "operands must be 16-byte aligned");
   const long Wp = Wd + 2;
   MGX_REQUIRE((long)(H + 2) * Wp * C * 2 < (1L << 32) && (long)Cout * 9 * C * 2 < (1L << 32), "image too large for one call");
-  GemmArgs g;
+  GemmArgs g{};
   g.A = x; g.W = Wt; g.bias = bias; g.C = out; g.gate = residual ? ones : nullptr; g.aux = nullptr; g.ldaux = 0; g.gate_ld = 0;
   g.M = H * Wd; g.N = Cout; g.K = 9 * C;
   g.a = RowMap{C, Wd, Wp * C};                      // output pixel (y, x) -> padded pixel (y, x): tap (0, 0)

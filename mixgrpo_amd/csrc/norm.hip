@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
   const int t0 = blockIdx.x * 64;
   const int HD = 128;
   const long dmodel = (long)a.H * HD;
+  const bool has_v = a.Vt != nullptr;             // null: V^T came straight from the projection (mgx_linear_bf16_t)
   const float wq0 = a.wq[2 * lane] * a.q_scale, wq1 = a.wq[2 * lane + 1] * a.q_scale;   // (x 1 is exact)
   const float wk0 = a.wk[2 * lane], wk1 = a.wk[2 * lane + 1];
   // four tokens per pass, every load of the pass issued before the first use: a wave instruction of this kernel moves 256 bytes
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       const bf16_raw* base = a.qkv + row * a.ld + hh * HD + 2 * lane;
       uq[u] = *reinterpret_cast<const uint32_t*>(base);
       uk[u] = *reinterpret_cast<const uint32_t*>(base + dmodel);
-      uv[u] = *reinterpret_cast<const uint32_t*>(base + 2 * dmodel);
+      uv[u] = has_v ? *reinterpret_cast<const uint32_t*>(base + 2 * dmodel) : 0u;
       const long so = (long)(a.s0 + tc) * HD + 2 * lane;
       cc[u] = *reinterpret_cast<const float2*>(a.cos + so);
       ss[u] = *reinterpret_cast<const float2*>(a.sin + so);
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       if (!ok[u]) continue;                                        // wave-uniform
       const int tl = w * 16 + i0 + u;
       const int s = a.s0 + t0 + tl;
-      *reinterpret_cast<uint32_t*>(&vt[tl][2 * lane]) = uv[u];
+      if (has_v) *reinterpret_cast<uint32_t*>(&vt[tl][2 * lane]) = uv[u];
       const float c0 = cc[u].x, c1 = cc[u].y, s0 = ss[u].x, s1 = ss[u].y;
       const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
       {
@@ -309,6 +310,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       if (EMIT_T) *reinterpret_cast<uint32_t*>(a.V + o) = uv[u];
     }
   }
+  if (!EMIT_T && !has_v) return;                  // (uniform over the grid)
   __syncthreads();
   // transposed tiles: Xt[b, h, d, s0 + t0 + 0..63] <- tile[t][d]
   const int ntok = min(64, a.rows_per_batch - t0);
@@ -509,8 +511,9 @@ extern "C" int mgx_qk_norm_rope_fwd_qs(const uint16_t* qkv, long ld, const float
                                        const float* sin, uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* V, uint16_t* Qt,
                                        uint16_t* Kt, int B, int H, int S, int Sp, int rows_per_batch, int s0, float q_scale,
                                        void* stream) {
-  MGX_REQUIRE(qkv && wq && wk && cos && sin && Q && K && Vt, "null argument");
+  MGX_REQUIRE(qkv && wq && wk && cos && sin && Q && K, "null argument");
   MGX_REQUIRE((V != nullptr) == (Qt != nullptr) && (V != nullptr) == (Kt != nullptr), "V, Qt, Kt come together");
+  MGX_REQUIRE(Vt || !V, "Vt may only be left out (V^T written by mgx_linear_bf16_t) without the backward's extra layouts");
   MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Sp >= S, "bad sizes");
   MGX_REQUIRE(ld == 3L * H * 128, "qkv rows must be [q | k | v] of H*128 each");
   MGX_REQUIRE(q_scale > 0.f, "q_scale must be positive");

@@ -368,6 +368,21 @@ class FluxTransformer2DModel(torch.nn.Module):
         else:
             ops.attn_fwd(w.Q, w.K, w.Vt, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
 
+    def _qkv_nograd(self, nrm, first, qkv, w, rows, s0):
+        """Fused q | k | v projection of one stream ([tokens, d] -> `qkv` [tokens, 3d]) for a forward that keeps nothing.  When
+        the persistent GEMM takes the shape, the value projection is issued with the operand roles swapped and lands
+        transposed in `w.Vt` [B, H, 128, Sp] at sequence offset `s0` (`mgx_linear_bf16_t`), only the q | k columns of `qkv`
+        are written, and the caller's `qk_norm_rope` is told to leave V alone (returns True)."""
+        d = self.cfg.dim
+        Wf = self.store.fused(self.store.w16, f"{first}.weight", 3 * d)
+        bf = self.store.fused(self.store.w16, f"{first}.bias", 3 * d)
+        tokens = nrm.numel() // d
+        if ops.LINEAR_VT and ops.linear_t(nrm, Wf[2 * d:], bf[2 * d:], w.Vt.view(-1)[s0:], tokens, d, d, w.Sp, rows, d * w.Sp):
+            ops.gemm(Rows.of(nrm), Wf[:2 * d], bf[:2 * d], Rows(qkv, tokens, 3 * d), 2 * d, d)
+            return True
+        ops.gemm(Rows.of(nrm), Wf, bf, Rows.of(qkv), 3 * d, d)
+        return False
+
     def q_scale(self):
         """What `mgx_qk_norm_rope_fwd_qs` multiplies q by before its one bf16 rounding: softmax scale * log2(e) (the scores
         are exponents of two: mgx_attn_fwd_log2), or 1 under MGX_ATTN_Q_PRESCALE=0."""
@@ -462,14 +477,19 @@ class FluxTransformer2DModel(torch.nn.Module):
             mods[name] = m
             Xs = self._stream_rows(w.X if x_in is None else x_in, w, name, d)
             ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm1[sl[name]], d)
-        if not (replay and qkv_kept):
+        vt_direct = {}
+        if save is None and keep is None:
+            # no-grad forward (the rollout): V^T straight from the value projection, the q | k columns alone through the norm pass
+            for name, _, qkvn, _, _, _, _, rows, s0 in streams:
+                vt_direct[name] = self._qkv_nograd(nrm1[sl[name]], f"{p}.attn.{qkvn[0]}", qkv_buf[sl[name]], w, rows, s0)
+        elif not (replay and qkv_kept):
             # both streams' fused QKV projections in one launch (text rows ride the image stream's rounds)
             ops.gemm_pair(*(x for name, _, qkvn, *_ in streams for x in (
                 Rows.of(nrm1[sl[name]]), fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
                 fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv_buf[sl[name]]))), 3 * d, d)
         for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
             ops.qk_norm_rope(qkv_buf[sl[name]], self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
-                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale(),
+                             w.Q, w.K, None if vt_direct.get(name) else w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale(),
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         # the attention output lives in the block's keep buffer when there is one (written here, read by the backward):
         # no copy between the workspace and the kept tensor
@@ -531,7 +551,10 @@ class FluxTransformer2DModel(torch.nn.Module):
         ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, nrm, d)
         qkv_kept = keep is not None and "qkv" in keep           # as in `_double_block`
         qkv = keep["qkv"] if qkv_kept else w.qkv
-        if not (replay and qkv_kept):
+        vt_direct = False
+        if save is None and keep is None:
+            vt_direct = self._qkv_nograd(nrm, f"{p}.attn.to_q", qkv, w, S, 0)
+        elif not (replay and qkv_kept):
             ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
                      self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(qkv), 3 * d, d)
         cat2 = w.cat.view(M, 5 * d)
@@ -544,7 +567,7 @@ class FluxTransformer2DModel(torch.nn.Module):
                      Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
                      aux=save["hid_pre"] if save is not None else (keep["hid_pre"] if ff_kept else None))
         ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
-                         w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0, q_scale=self.q_scale(),
+                         w.Q, w.K, None if vt_direct else w.Vt, B, H, S, w.Sp, S, 0, q_scale=self.q_scale(),
                          **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward
             if not ff_kept:

@@ -44,6 +44,30 @@ def gemm(A: Rows, W, bias, C: Rows, N, K, epi=EPI_BIAS, gate=None, gate_ld=0, au
 
 GEMM_PROFILE = None
 
+# MGX_LINEAR_VT=0: the value projection always leaves row-major and mgx_qk_norm_rope_fwd transposes it (the training passes
+# do that anyway: their backward needs V row-major as well)
+LINEAR_VT = os.environ.get("MGX_LINEAR_VT", "1") != "0"
+
+
+def linear_t(X, W, bias, Ct, tokens, F, K, ld_ct, tok_rpb, ct_bstride):
+    """Ct[b][f][t] = bf16(X[b * tok_rpb + t] . W[f] + bias[f]) (`mgx_linear_bf16_t`: a Linear whose output leaves transposed,
+    token-contiguous).  X plain [tokens, K], W [F, K]; Ct: a tensor whose data_ptr() is the element of (b 0, f 0, t 0).
+    False -- nothing launched -- when the persistent kernel cannot take the shape."""
+    ws = _sk_workspace(X.device) if GEMM_STREAM_K else None
+    prof = GEMM_PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().mgx_linear_bf16_t(ptr(X), ptr(W), ptr(bias), Ct.data_ptr(), tokens, F, K, K, K, ld_ct, tok_rpb, ct_bstride,
+                                 None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream())
+    if rc == 1:
+        return False
+    check(rc)
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * tokens * F * K, (F, tokens, K, EPI_BIAS)))
+    return True
+
 
 def _gemm_launch(A, W, bias, C, N, K, epi, gate, gate_ld, aux, beta, ldw, ldaux):
     ws = _sk_workspace(C.t.device) if GEMM_STREAM_K else None

@@ -252,3 +252,44 @@ def test_model_with_and_without_prescaled_q_agree_with_the_oracle(monkeypatch):
         assert torch.nn.functional.cosine_similarity(g, gref, dim=0).item() > 0.999
     assert T.rel_err(res[0][0], res[1][0]) < 8e-3
     assert torch.nn.functional.cosine_similarity(res[0][1], res[1][1], dim=0).item() > 0.9995
+
+
+def test_forward_with_v_transposed_by_the_projection_equals_the_transposing_pass(monkeypatch):
+    """The no-grad forward (rollout) with V^T written by mgx_linear_bf16_t + q | k-only norm pass against the same forward with
+    the fused q | k | v projection and mgx_qk_norm_rope_fwd's transposing pass (MGX_LINEAR_VT=0), at a size where the persistent
+    kernel takes the value projection (d = 512 would not: FLUX width, one double + one single block, 2 x (256 + 1024) tokens),
+    stream-K off: every output element is the same K-loop in the same order, so the outputs are equal BIT FOR BIT."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
+    cfg = dict(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=24, joint_attention_dim=64,
+               pooled_projection_dim=32)
+    torch.manual_seed(0)
+    m = FluxTransformer2DModel(FluxConfig(**cfg), device="cuda")
+    sd = {k: (torch.randn(v.shape, device="cuda") * (0.02 if v.dim() > 1 else 0.05) + (1.0 if "norm_" in k and v.dim() == 1 else 0.0))
+          for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.eval()
+    B, hg, wg, L = 8, 32, 32, 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, hg * wg, 64, generator=g).cuda()
+    ehs = torch.randn(B, L, 64, generator=g).bfloat16().cuda()
+    pooled = torch.randn(B, 32, generator=g).bfloat16().cuda()
+    ids = torch.zeros(hg, wg, 3)
+    ids[..., 1] += torch.arange(hg)[:, None]
+    ids[..., 2] += torch.arange(wg)[None]
+    ids = ids.reshape(-1, 3).cuda()
+    t = torch.full((B,), 0.7).cuda()
+    gd = torch.tensor([3.5]).bfloat16().cuda()
+    monkeypatch.setattr(ops, "GEMM_STREAM_K", False)
+    calls = []
+    real = ops.linear_t
+    monkeypatch.setattr(ops, "linear_t", lambda *a, **k: (calls.append(real(*a, **k)) or calls[-1]))
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "LINEAR_VT", on)
+        with torch.no_grad():
+            outs.append(m._forward_nograd(x, ehs, t, gd, torch.zeros(L, 3).cuda(), pooled, ids).clone())
+    # text stream: 8 x 256 tokens = 12 x 8 = 96 tiles, declined (plain path inside the same forward); image stream and the
+    # single block's joint sequence: taken
+    assert calls == [False, True, True]
+    assert torch.equal(outs[0], outs[1])

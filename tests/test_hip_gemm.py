@@ -435,3 +435,53 @@ def test_transpose_with_gelu_equals_gelu_then_transpose(M, N):
     ref = torch.nn.functional.gelu(x.float(), approximate="tanh")
     assert ((got[:, :M].t().float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
     assert (got[:, M:] == 0).all()
+
+
+@pytest.mark.parametrize("B,rows,F,K,s0,Sp", [(8, 512, 3072, 1024, 0, 4608), (4, 2048, 1536, 512, 512, 2560), (1, 36864 // 8, 3072, 256, 0, 4608),
+                                              (3, 1024 + 64, 3072, 4096, 64, 1216)])
+@pytest.mark.parametrize("sk", [False, True])
+def test_linear_t_writes_the_transposed_projection(B, rows, F, K, s0, Sp, sk):
+    """mgx_linear_bf16_t (the value projection landing as V^T [B, F, Sp] at sequence offset s0: operand roles swapped, row-wise
+    bias, column batches) against the plain Linear of the same operands, transposed on the host.  Without the stream-K tail
+    both forms run every output element's K-loop whole and in the same order: equal BIT FOR BIT; with it, to summation-order
+    accuracy (one bf16 ulp on isolated elements).  Everything outside columns s0 .. s0 + rows stays untouched."""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(B + rows + F + K)
+    tokens = B * rows
+    X = (torch.randn(tokens, K, generator=g) * 0.5).bfloat16().cuda()
+    W = (torch.randn(F, K, generator=g) * 0.05).bfloat16().cuda()
+    bias = (torch.randn(F, generator=g) * 0.3).bfloat16().cuda()
+    sk_default = ops.GEMM_STREAM_K
+    ops.GEMM_STREAM_K = sk
+    try:
+        Ct = torch.full((B, F, Sp), 7.0, dtype=torch.bfloat16, device="cuda")
+        assert ops.linear_t(X, W, bias, Ct.view(-1)[s0:], tokens, F, K, Sp, rows, F * Sp)
+        C = torch.empty(tokens, F, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(Rows.of(X), W, bias, Rows.of(C), F, K)
+    finally:
+        ops.GEMM_STREAM_K = sk_default
+    want = C.view(B, rows, F).transpose(1, 2)
+    got = Ct[:, :, s0:s0 + rows]
+    assert (Ct[:, :, :s0] == 7.0).all() and (Ct[:, :, s0 + rows:] == 7.0).all()
+    ref = (X.float() @ W.float().t() + bias.float()).view(B, rows, F).transpose(1, 2)
+    assert ((got.float() - ref).norm() / ref.norm()).item() < 3e-3
+    if not sk:
+        assert torch.equal(got, want)
+    else:
+        assert ((got.float() - want.float()).abs() <= 0.0079 * want.float().abs() + 1e-6).all()     # <= 1 bf16 ulp
+        assert (got != want).float().mean().item() < 1e-2
+
+
+def test_linear_t_declines_what_the_persistent_kernel_cannot_take():
+    """Fewer than 128 output tiles / token batches that are no multiple of 64: returns False and writes nothing (the caller keeps
+    the plain projection and the transposing pass)."""
+    from mixgrpo_amd import ops
+    X = torch.zeros(512, 256, dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros(3072, 256, dtype=torch.bfloat16, device="cuda")
+    Ct = torch.full((1, 3072, 512), 7.0, dtype=torch.bfloat16, device="cuda")
+    assert not ops.linear_t(X, W, None, Ct, 512, 3072, 256, 512, 512, 3072 * 512)            # 24 tiles
+    X = torch.zeros(8 * 1000, 256, dtype=torch.bfloat16, device="cuda")
+    Ct = torch.full((8, 3072, 1024), 7.0, dtype=torch.bfloat16, device="cuda")
+    assert not ops.linear_t(X, W, None, Ct, 8000, 3072, 256, 1024, 1000, 3072 * 1024)        # 1000 % 64 != 0
+    assert (Ct == 7.0).all()
