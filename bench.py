@@ -250,14 +250,18 @@ def main():
             cpu_child.kill()
             cpu_measured = None
     fence()
+    ms0 = torch.cuda.memory_stats()
+    step_s = []
     t0 = time.perf_counter()
     for i in range(a.steps):
         t1 = time.perf_counter()
         last = one_step()
+        step_s.append(time.perf_counter() - t1)
         if rank == 0 and (i + 1) % 2 == 0:  # a progress line every other step, from host time only (no device sync)
             progress("timed", i, a.steps, (time.perf_counter() - t1))
     fence()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -352,6 +356,12 @@ def main():
                 "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "hbm_reserved_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                 "hbm_free_gib": round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1),
+                # allocator traffic INSIDE the timed region (device mallocs / frees / out-of-memory retries of torch's caching
+                # allocator) and the host-side time of each timed step (enqueue time: no device sync between steps)
+                "allocator_in_timed_region": {k: ms1.get(k2, 0) - ms0.get(k2, 0) for k, k2 in
+                                              (("device_alloc", "num_device_alloc"), ("device_free", "num_device_free"),
+                                               ("alloc_retries", "num_alloc_retries"), ("ooms", "num_ooms"))},
+                "host_s_per_timed_step": [round(x, 2) for x in step_s],
                 "last_step": {"loss": last[0][0], "grad_norm": last[0][1], "clip_frac": last[0][4],
                               "note": "grad_norm = norm of the step's last optimizer update, 0.0 when every pair of that "
                                       "chunk is PPO-clipped at clip_range 1e-4 (DESIGN.md section 6)"} if last else None,

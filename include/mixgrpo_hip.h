@@ -159,6 +159,17 @@ int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias,
                      uint16_t* aux, long ldaux, int M, int N, int K, long lda, long a_rpb, long a_bstride, long ldw, long ldc,
                      long c_rpb, long c_bstride, long gate_ld, int epilogue, float beta, float* sk_workspace,
                      long sk_workspace_elems, void* stream);
+/* The q | k projection of an attention layer with mgx_qk_norm_rope_fwd_qs applied in the GEMM's epilogue, on the tile while
+ * it is in registers: X [B * rows_per_batch, K] (plain), Wqk [2 * H * 128, K] (to_q rows, then to_k rows), bias [2 * H * 128]
+ * -> Q, K [B, H, S, 128] at sequence positions s0 .. s0 + rows_per_batch - 1, Q times q_scale.  The [tokens, 2 H 128]
+ * projection output is neither written nor re-read.  Same bits as mgx_gemm_bf16 followed by mgx_qk_norm_rope_fwd_qs
+ * (diffusers' to_q / to_k Linears + norm_q / norm_k + apply_rotary_emb; call sites fastvideo/utils/sampling_utils.py:68-82).
+ * Returns 1 -- nothing launched -- when the persistent kernel cannot take the problem (fewer than 128 output tiles of
+ * 256 x 256, H odd, rows_per_batch % 128 != 0, alignments below 16 bytes, MGX_GEMM_QKNORM=0): keep the two-pass form. */
+int mgx_linear_qk_norm_rope(const uint16_t* X, const uint16_t* Wqk, const uint16_t* bias, const float* wq, const float* wk,
+                            const float* cos, const float* sin, uint16_t* Q, uint16_t* K, int B, int H, int S,
+                            int rows_per_batch, int s0, int Kdim, long ldx, long ldw, float q_scale, void* stream);
+
 /* A Linear whose output leaves TRANSPOSED: Ct[b][f][t] = bf16(X[b * tok_rpb + t, :] . W[f, :] + bias[f]), ld_ct elements
  * between feature rows, ct_bstride between token batches -- the V^T [B, H, 128, Sp] operand of mgx_attn_fwd* straight from
  * the value projection (the nn.Linear to_v / add_v_proj of diffusers' FluxAttnProcessor2_0 followed by the transpose SDPA's

@@ -36,7 +36,8 @@ __device__ __forceinline__ long row_off(const RowMap& r, long m) {
   return (long)b * r.bstride + (long)((uint32_t)m - b * rpb) * r.ld;
 }
 
-enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2, EPI_F32_ACC = 3, EPI_BIAS_MULAUX = 4 };
+enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2, EPI_F32_ACC = 3, EPI_BIAS_MULAUX = 4,
+           EPI_QKNORM = 5 /* internal (mgx_linear_qk_norm_rope): bias, per-head RMSNorm, RoPE, head split */ };
 
 struct GemmArgs {
   const bf16_raw* A;
@@ -81,6 +82,16 @@ struct GemmArgs {
   // column batch n / col_rpb at C + (n / col_rpb) * col_bstride + row offset + n % col_rpb (col_rpb % 64 == 0).
   int bias_rows;
   long col_rpb, col_bstride;
+  // EPI_QKNORM (mgx_linear_qk_norm_rope; persistent kernel only): the output columns are [q | k] of qn_dmodel = H * 128 each
+  // (qn_dmodel % 256 == 0: a tile lies in one section, a wave's 64 columns in one half of one head); c.rpb = tokens per sample
+  const float* qn_wq;     // [128] fp32 RMSNorm weights
+  const float* qn_wk;
+  const float* qn_cos;    // [S, 128] fp32
+  const float* qn_sin;
+  bf16_raw* qn_Q;         // [B, H, S, 128]
+  bf16_raw* qn_K;
+  int qn_H, qn_S, qn_s0, qn_dmodel;
+  float qn_qscale;
 };
 
 // operands of the problem that tile row m0 belongs to (PAIR launches), as a GemmArgs the ordinary epilogue can take
@@ -461,9 +472,171 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return o;
 }
 
+// EPI_QKNORM: what mgx_qk_norm_rope_fwd does to the q | k columns, on the tile while it is in registers -- the [tokens, 2d]
+// projection output is never written and never re-read (the rollout's norm pass was 0.35 s of an 18.3 s step at HBM speed).
+// The arithmetic is that kernel's, operation for operation and in its summation order (norm.hip head_sum: the butterfly over
+// the 64 rotation pairs of a head in the bit order 0, 1, 4, 2, 3, 5 of the pair index), on the bf16-ROUNDED Linear output, with
+// no contraction: both paths give the same bits (tests/test_hip_gemm.py).  A head's 128 features are two waves' columns
+// (wn, wn ^ 1): the half-head sums of squares cross through LDS with ONE workgroup barrier -- every wave of the workgroup runs
+// it exactly once per tile, so the early / late halves of the K-loop stay one barrier apart.  `red`: the A stage the NEXT
+// K-tile DMA will fill; a wave's sums are written where its PARTNER's first DMA piece lands (bytes (wu ^ 1) * 1024 ..), so only
+// the reader itself can overwrite them, after it has read.
+__device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int wid, int lane, long m0, long n0,
+                                                char* red) {
+#pragma clang fp contract(off)
+  constexpr int MT = 8;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const long nu = n0 + (wu & 3) * 64;
+  long mu = m0 + (wu >> 2) * 128;
+  const bool inside = mu < g.M;                       // M % 128 == 0 (entry): a wave's rows are all inside or all outside
+  if (!inside) mu = g.M - 128;                        // (outside: same work on clamped addresses, no stores -- the barrier is for all)
+  const int sec = nu >= g.qn_dmodel ? 1 : 0;
+  const int hcol = (int)(nu - (long)sec * g.qn_dmodel);
+  const int head = hcol >> 7, hb = hcol & 64;
+  const uint32_t bu = (uint32_t)mu / (uint32_t)g.c.rpb;
+  const int t0 = (int)((uint32_t)mu - bu * (uint32_t)g.c.rpb);
+  const int f0 = lane_feat(fq, 0), f1 = lane_feat(fq, 2);
+  uint4 bias0 = make_uint4(0, 0, 0, 0), bias1 = bias0;
+  if (g.bias) {
+    bias0 = *reinterpret_cast<const uint4*>(g.bias + nu + f0);
+    bias1 = *reinterpret_cast<const uint4*>(g.bias + nu + f1);
+  }
+  // cos / sin rows of the lane: sequence position s0 + t0 + fr + 16 j, features hb + f0 .. +7 and hb + f1 .. +7
+  const float* cbase = g.qn_cos + (long)(g.qn_s0 + t0 + fr) * 128 + hb;
+  const float* sbase = g.qn_sin + (long)(g.qn_s0 + t0 + fr) * 128 + hb;
+  // ring of table rows in flight, one row ahead of the arithmetic.  The epilogue's cost IS these loads -- 512 KiB per tile through
+  // the CU's L1: 1.164 ms fused, 1.037 ms without them, 1.020 ms the plain projection, 0.212 ms the norm pass it replaces
+  // (profiles/r04_qknorm_epilogue_prices.log).  A (cos, sin)-per-pair table (FLUX's tables repeat every pair's entry: half the
+  // bytes) two rows ahead was built and measured: 1.217 ms as hipcc compiles it (200 bytes of spills per lane), 1.123 ms under
+  // -fno-slp-vectorize, which costs this general form 0.07 ms -- not kept.
+  constexpr int AHEAD = 1, NSLOT = AHEAD + 1;
+  float4 cs[NSLOT][8];                                // [ring slot][cos f0, cos f0+4, cos f1, cos f1+4, sin ...]
+  auto load_cs = [&](int slot, int j, uint32_t dep) {
+#ifdef MGX_DIAG_QKN_NOLOAD      // scratch/qkn_diag.py only: price of the cos / sin loads (wrong results)
+    for (int q_ = 0; q_ < 8; ++q_) cs[slot][q_] = make_float4(0.5f + dep, 0.25f, 0.5f, 0.25f);
+    return;
+#endif
+    const long o = (long)(j * 16 + dep) * 128;
+    cs[slot][0] = *reinterpret_cast<const float4*>(cbase + o + f0);
+    cs[slot][1] = *reinterpret_cast<const float4*>(cbase + o + f0 + 4);
+    cs[slot][2] = *reinterpret_cast<const float4*>(cbase + o + f1);
+    cs[slot][3] = *reinterpret_cast<const float4*>(cbase + o + f1 + 4);
+    cs[slot][4] = *reinterpret_cast<const float4*>(sbase + o + f0);
+    cs[slot][5] = *reinterpret_cast<const float4*>(sbase + o + f0 + 4);
+    cs[slot][6] = *reinterpret_cast<const float4*>(sbase + o + f1);
+    cs[slot][7] = *reinterpret_cast<const float4*>(sbase + o + f1 + 4);
+  };
+  // y = bf16(acc + bias), the value the unfused path stores and reads back
+  uint4 y[MT][2];
+  {
+    float bias[16];
+    unpack8(bias0, bias);
+    unpack8(bias1, bias + 8);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
+      y[j][0] = pack8(v);
+      y[j][1] = pack8(v + 8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // (only now, with the 128 accumulator registers retired into 64: the first table rows and the norm weights; the sums of
+  //  squares and the exchange below cover their latency)
+  // RMSNorm weights of the lane's 16 features (q: times q_scale, as mgx_qk_norm_rope_fwd_qs folds it)
+  uint32_t dep0 = 0;                                  // an opaque zero that exists only once y is complete: pins the loads below
+  asm volatile("" : "+v"(dep0) : "v"(y[MT - 1][1].w));   // behind the accumulators' retirement (they were hoisted above it, into spills)
+  float wv[16];
+  {
+    const float* wp = (sec ? g.qn_wk : g.qn_wq) + hb + dep0;
+    const float4 a0 = *reinterpret_cast<const float4*>(wp + f0), a1 = *reinterpret_cast<const float4*>(wp + f0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(wp + f1), b1 = *reinterpret_cast<const float4*>(wp + f1 + 4);
+    const float t[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float qs = sec ? 1.0f : g.qn_qscale;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) wv[e] = t[e] * qs;
+  }
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j) load_cs(j, j, dep0);
+  __builtin_amdgcn_sched_barrier(0);
+  // sums of squares of the wave's half head, per row
+  float ssq[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    float x[16], p[8];
+    unpack8(y[j][0], x);
+    unpack8(y[j][1], x + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+    float sacc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));     // pair-index bits 0, 1, then 4
+    sacc += __shfl_xor(sacc, 16, 64);                                                   // bit 2
+    sacc += __shfl_xor(sacc, 32, 64);                                                   // bit 3
+    ssq[j] = sacc;
+    if (j & 1) __builtin_amdgcn_sched_barrier(0);     // two rows at a time: all eight interleaved unpack into 128 registers and spill
+  }
+  {
+    float* wr = reinterpret_cast<float*>(red + (wu ^ 1) * 1024);
+    const float* rd = reinterpret_cast<const float*>(red + wu * 1024);
+    if (fq == 0) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) wr[fr + 16 * j] = ssq[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef MGX_DIAG_QKN_NOBAR      // scratch/qkn_diag.py only: price of the exchange barrier (wrong results)
+    __builtin_amdgcn_s_barrier();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) ssq[j] = ssq[j] + rd[fr + 16 * j];                     // bit 5: the other half of the head
+  }
+  bf16_raw* out = (sec ? g.qn_K : g.qn_Q) + (((long)bu * g.qn_H + head) * g.qn_S + g.qn_s0 + t0 + fr) * 128 + hb;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int slot = j % NSLOT;
+    if (j + AHEAD < MT) {
+      uint32_t dep = 0;
+      if (j > 0) asm volatile("" : "+v"(dep) : "v"(y[j - 1][1].w));     // keeps the loads from being hoisted above row j - 1
+      load_cs((j + AHEAD) % NSLOT, j + AHEAD, dep);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float r = rsqrtf(ssq[j] / 128.f + 1e-6f);
+    float x[16], o[16];
+    unpack8(y[j][0], x);
+    unpack8(y[j][1], x + 8);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 cv = cs[slot][q4], sv = cs[slot][4 + q4];
+      const float c[4] = {cv.x, cv.y, cv.z, cv.w}, sn[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * q4 + h;
+        const float y0 = x[2 * i] * r * wv[2 * i], y1 = x[2 * i + 1] * r * wv[2 * i + 1];
+        o[2 * i] = y0 * c[2 * h] - y1 * sn[2 * h];
+        o[2 * i + 1] = y1 * c[2 * h + 1] + y0 * sn[2 * h + 1];
+      }
+    }
+    y[j][0] = pack8(o);
+    y[j][1] = pack8(o + 8);
+    if (inside) {
+      *reinterpret_cast<uint4*>(out + (long)j * 16 * 128 + f0) = y[j][0];
+      *reinterpret_cast<uint4*>(out + (long)j * 16 * 128 + f1) = y[j][1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int EPI>
 __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int wid, int lane, long m0,
-                                                 long n0) {
+                                                 long n0, char* red = nullptr) {
+  if constexpr (EPI == EPI_QKNORM) {
+    qknorm_epilogue(g, acc, wid, lane, m0, n0, red);
+    return;
+  }
   constexpr int MT = 8;
   const int wm = wid >> 2, wn = wid & 3, fr = lane & 15, fq = lane >> 4;
   const long nw = n0 + wn * 64;                   // the wave's 64 output features; tile t of this lane: nw + lane_feat(fq, t)
@@ -798,7 +971,7 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   long m0 = (long)(b0 * band + in_band % rows_in_band) * 256;
   const long n0 = (long)(in_band / rows_in_band) * 256;
   const GemmArgs gl = seg_args<PAIR>(g, m0);
-  persist_epilogue<EPI>(gl, acc, wid, lane, m0, n0);
+  if constexpr (EPI != EPI_QKNORM) persist_epilogue<EPI>(gl, acc, wid, lane, m0, n0);   // (QKNORM launches never split: launch())
 }
 
 // ------------------------------------------------------------------------------------------ persistent ping-pong kernel
@@ -1029,7 +1202,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(GemmArgs g) {
       const GemmArgs gl = seg_args<true>(g, m0l);
       persist_epilogue<EPI>(gl, acc, ew, el, m0l, n0);
     } else {
-      persist_epilogue<EPI>(g, acc, ew, el, m0, n0);
+      // (EPI_QKNORM: the A stage the next K-tile's DMA will fill -- its last readers, the late half's LB of this tile's last
+      //  K-tile, are one barrier back for the early half and two for the late one)
+      persist_epilogue<EPI>(g, acc, ew, el, m0, n0, smem + (aslot == 0 ? 2 : aslot - 1) * TB);
     }
     if (!has_next) break;
     ++ui;
@@ -1084,6 +1259,7 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
     attr_set = true;
   }
   const bool pair = !CONV && g.m_split != 0;
+  if (EPI == EPI_QKNORM) g.sk_ws = nullptr;          // its epilogue needs the whole workgroup: no split tiles
   if (persistent_ok(g)) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     // stream-K tail (caller gave a workspace): allowed when it shortens the launch.  A tile's K-loop takes T ~ K * 0.0247 us
@@ -1301,6 +1477,40 @@ extern "C" int mgx_linear_bf16_t(const uint16_t* X, const uint16_t* W, const uin
   g.span32 = ((long)F * ldw) * 2 < (1L << 32) && ((long)tokens * ldx) * 2 < (1L << 32);
   if (!persistent_ok(g)) return 1;
   return launch<EPI_BIAS>(g, (hipStream_t)stream);
+}
+
+// The q | k projection of an attention layer with mgx_qk_norm_rope_fwd_qs applied in the GEMM's epilogue: X [tokens, K] (plain,
+// B samples of rows_per_batch tokens each), Wqk [2 * H * 128, K] (the to_q rows, then the to_k rows), bias [2 * H * 128] ->
+// Q, K [B, H, S, 128] at sequence positions s0 .. s0 + rows_per_batch - 1, Q times q_scale.  Same bits as the plain Linear
+// followed by mgx_qk_norm_rope_fwd_qs.  Returns 1 -- nothing launched -- when the persistent kernel cannot take the problem
+// (fewer than 128 tiles of 256 x 256, H odd, rows_per_batch % 128 != 0, alignments): the caller keeps the two-pass form.
+extern "C" int mgx_linear_qk_norm_rope(const uint16_t* X, const uint16_t* Wqk, const uint16_t* bias, const float* wq,
+                                       const float* wk, const float* cos, const float* sin, uint16_t* Q, uint16_t* K, int B,
+                                       int H, int S, int rows_per_batch, int s0, int Kdim, long ldx, long ldw, float q_scale,
+                                       void* stream) {
+  MGX_REQUIRE(X && Wqk && wq && wk && cos && sin && Q && K, "null argument");
+  MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Kdim > 0 && q_scale > 0.f, "bad sizes");
+  static const int off = getenv("MGX_GEMM_QKNORM") ? atoi(getenv("MGX_GEMM_QKNORM")) == 0 : 0;
+  const long tokens = (long)B * rows_per_batch;
+  const int dmodel = H * 128;
+  const bool ok = !off && dmodel % 256 == 0 && rows_per_batch % 128 == 0 && Kdim % BK == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
+                  tokens < (1L << 31) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Wqk % 16 == 0) && ((uintptr_t)Q % 16 == 0) &&
+                  ((uintptr_t)K % 16 == 0) && ((uintptr_t)cos % 16 == 0) && ((uintptr_t)sin % 16 == 0) &&
+                  ((uintptr_t)wq % 16 == 0) && ((uintptr_t)wk % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+  if (!ok) return 1;
+  GemmArgs g{};
+  g.A = X; g.W = Wqk; g.bias = bias; g.C = Q;
+  g.M = (int)tokens; g.N = 2 * dmodel; g.K = Kdim;
+  g.a = RowMap{ldx, 1L << 30, 0};
+  g.c = RowMap{128, rows_per_batch, 0};
+  g.ldw = ldw;
+  g.conv_shift = -1;
+  g.rowwise_ok = 1;
+  g.span32 = (tokens * ldx) * 2 < (1L << 32) && ((long)g.N * ldw) * 2 < (1L << 32);
+  g.qn_wq = wq; g.qn_wk = wk; g.qn_cos = cos; g.qn_sin = sin; g.qn_Q = Q; g.qn_K = K;
+  g.qn_H = H; g.qn_S = S; g.qn_s0 = s0; g.qn_dmodel = dmodel; g.qn_qscale = q_scale;
+  if (!persistent_ok(g)) return 1;
+  return launch<EPI_QKNORM>(g, (hipStream_t)stream);
 }
 
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,

@@ -248,6 +248,19 @@ struct QkArgs {
   float q_scale;       // Q (and Qt) leave as bf16(q * q_scale): 1, or softmax scale * log2(e) for mgx_attn_fwd_log2
 };
 
+// Sum over the 64 rotation pairs of a head (lane = pair): the butterfly in the bit order 0, 1, 4, 2, 3, 5 of the pair index --
+// the order in which the GEMM epilogue that does this kernel's work on the tile (gemm.hip, EPI_QKNORM) meets the pairs: four per
+// lane and feature group, two groups per lane, four lanes, two waves.  Same tree, same bits.
+__device__ __forceinline__ float head_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 template <bool EMIT_T>
 __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
   __shared__ bf16_raw vt[64][130];
@@ -293,7 +306,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       const long o = (((long)b * a.H + hh) * a.S + s) * HD + 2 * lane;
       {
         const float x0 = bf2f(uq[u] & 0xffff), x1 = bf2f(uq[u] >> 16);
-        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        const float r = rsqrtf(head_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
         const float y0 = x0 * r * wq0, y1 = x1 * r * wq1;
         const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
         *reinterpret_cast<uint32_t*>(a.Q + o) = pk;
@@ -301,7 +314,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(QkArgs a) {
       }
       {
         const float x0 = bf2f(uk[u] & 0xffff), x1 = bf2f(uk[u] >> 16);
-        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        const float r = rsqrtf(head_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
         const float y0 = x0 * r * wk0, y1 = x1 * r * wk1;
         const uint32_t pk = (uint32_t)f2bf(y0 * c0 - y1 * s0) | ((uint32_t)f2bf(y1 * c1 + y0 * s1) << 16);
         *reinterpret_cast<uint32_t*>(a.K + o) = pk;
@@ -404,7 +417,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(QkBwdArgs a) {
         // rope^T: out0 = y0 c0 - y1 s0 ; out1 = y1 c1 + y0 s1
         const float gy0 = go0 * c0 + go1 * s1;
         const float gy1 = -go0 * s0 + go1 * c1;
-        const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);
+        const float r = rsqrtf(head_sum(x0 * x0 + x1 * x1) / 128.f + 1e-6f);       // the forward's r, bit for bit
         // y = x * r * w
         if (which) { gk0 += gy0 * x0 * r; gk1 += gy1 * x1 * r; } else { gq0 += gy0 * x0 * r; gq1 += gy1 * x1 * r; }
         const float gz0 = gy0 * w0, gz1 = gy1 * w1;           // grad wrt (x*r)

@@ -368,20 +368,26 @@ class FluxTransformer2DModel(torch.nn.Module):
         else:
             ops.attn_fwd(w.Q, w.K, w.Vt, O, lse, w.B, H, w.S, w.Sp, ldo, o_bstride, scale)
 
-    def _qkv_nograd(self, nrm, first, qkv, w, rows, s0):
-        """Fused q | k | v projection of one stream ([tokens, d] -> `qkv` [tokens, 3d]) for a forward that keeps nothing.  When
-        the persistent GEMM takes the shape, the value projection is issued with the operand roles swapped and lands
-        transposed in `w.Vt` [B, H, 128, Sp] at sequence offset `s0` (`mgx_linear_bf16_t`), only the q | k columns of `qkv`
-        are written, and the caller's `qk_norm_rope` is told to leave V alone (returns True)."""
-        d = self.cfg.dim
+    def _qkv_nograd(self, nrm, first, qkv, w, rows, s0, wq, wk, cos, sin):
+        """Fused q | k | v projection of one stream ([tokens, d] -> `qkv` [tokens, 3d]) + QK-norm / RoPE / head split for a
+        forward that keeps nothing (the rollout).  When the persistent GEMM takes the shapes: the value projection is issued
+        with the operand roles swapped and lands transposed in `w.Vt` [B, H, 128, Sp] at sequence offset `s0`
+        (`mgx_linear_bf16_t`), and the q | k projection normalises, rotates and head-splits its tile in the epilogue
+        (`mgx_linear_qk_norm_rope`: `qkv` is not touched at all).  Otherwise the plain projection(s) and the norm pass."""
+        d, H = self.cfg.dim, self.cfg.num_attention_heads
         Wf = self.store.fused(self.store.w16, f"{first}.weight", 3 * d)
         bf = self.store.fused(self.store.w16, f"{first}.bias", 3 * d)
         tokens = nrm.numel() // d
-        if ops.LINEAR_VT and ops.linear_t(nrm, Wf[2 * d:], bf[2 * d:], w.Vt.view(-1)[s0:], tokens, d, d, w.Sp, rows, d * w.Sp):
+        B = tokens // rows
+        vt = ops.LINEAR_VT and ops.linear_t(nrm, Wf[2 * d:], bf[2 * d:], w.Vt.view(-1)[s0:], tokens, d, d, w.Sp, rows, d * w.Sp)
+        if vt and ops.LINEAR_QKNORM and H * 128 == d and ops.linear_qk_norm_rope(
+                nrm, Wf[:2 * d], bf[:2 * d], wq, wk, cos, sin, w.Q, w.K, B, H, w.S, rows, s0, d, q_scale=self.q_scale()):
+            return
+        if vt:
             ops.gemm(Rows.of(nrm), Wf[:2 * d], bf[:2 * d], Rows(qkv, tokens, 3 * d), 2 * d, d)
-            return True
-        ops.gemm(Rows.of(nrm), Wf, bf, Rows.of(qkv), 3 * d, d)
-        return False
+        else:
+            ops.gemm(Rows.of(nrm), Wf, bf, Rows.of(qkv), 3 * d, d)
+        ops.qk_norm_rope(qkv, wq, wk, cos, sin, w.Q, w.K, None if vt else w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale())
 
     def q_scale(self):
         """What `mgx_qk_norm_rope_fwd_qs` multiplies q by before its one bf16 rounding: softmax scale * log2(e) (the scores
@@ -477,19 +483,20 @@ class FluxTransformer2DModel(torch.nn.Module):
             mods[name] = m
             Xs = self._stream_rows(w.X if x_in is None else x_in, w, name, d)
             ops.ln_modulate(Xs, m[:, 0:d], m[:, d:2 * d], 6 * d, nrm1[sl[name]], d)
-        vt_direct = {}
-        if save is None and keep is None:
-            # no-grad forward (the rollout): V^T straight from the value projection, the q | k columns alone through the norm pass
-            for name, _, qkvn, _, _, _, _, rows, s0 in streams:
-                vt_direct[name] = self._qkv_nograd(nrm1[sl[name]], f"{p}.attn.{qkvn[0]}", qkv_buf[sl[name]], w, rows, s0)
+        nograd = save is None and keep is None
+        if nograd:
+            # no-grad forward (the rollout): V^T straight from the value projection, QK-norm / RoPE in the q | k projection's epilogue
+            for name, _, qkvn, nq, nk, _, _, rows, s0 in streams:
+                self._qkv_nograd(nrm1[sl[name]], f"{p}.attn.{qkvn[0]}", qkv_buf[sl[name]], w, rows, s0,
+                                 self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin)
         elif not (replay and qkv_kept):
             # both streams' fused QKV projections in one launch (text rows ride the image stream's rounds)
             ops.gemm_pair(*(x for name, _, qkvn, *_ in streams for x in (
                 Rows.of(nrm1[sl[name]]), fused(self.store.w16, f"{p}.attn.{qkvn[0]}.weight", 3 * d),
                 fused(self.store.w16, f"{p}.attn.{qkvn[0]}.bias", 3 * d), Rows.of(qkv_buf[sl[name]]))), 3 * d, d)
-        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in streams:
+        for name, norm, qkvn, nq, nk, outn, ffn, rows, s0 in (() if nograd else streams):
             ops.qk_norm_rope(qkv_buf[sl[name]], self.W32(f"{p}.attn.{nq}.weight"), self.W32(f"{p}.attn.{nk}.weight"), cos, sin,
-                             w.Q, w.K, None if vt_direct.get(name) else w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale(),
+                             w.Q, w.K, w.Vt, B, H, w.S, w.Sp, rows, s0, q_scale=self.q_scale(),
                              **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         # the attention output lives in the block's keep buffer when there is one (written here, read by the backward):
         # no copy between the workspace and the kept tensor
@@ -551,9 +558,10 @@ class FluxTransformer2DModel(torch.nn.Module):
         ops.ln_modulate(Xa, m[:, 0:d], m[:, d:2 * d], 3 * d, nrm, d)
         qkv_kept = keep is not None and "qkv" in keep           # as in `_double_block`
         qkv = keep["qkv"] if qkv_kept else w.qkv
-        vt_direct = False
-        if save is None and keep is None:
-            vt_direct = self._qkv_nograd(nrm, f"{p}.attn.to_q", qkv, w, S, 0)
+        nograd = save is None and keep is None
+        if nograd:
+            self._qkv_nograd(nrm, f"{p}.attn.to_q", qkv, w, S, 0, self.W32(f"{p}.attn.norm_q.weight"),
+                             self.W32(f"{p}.attn.norm_k.weight"), cos, sin)
         elif not (replay and qkv_kept):
             ops.gemm(Rows.of(nrm), self.store.fused(self.store.w16, f"{p}.attn.to_q.weight", 3 * d),
                      self.store.fused(self.store.w16, f"{p}.attn.to_q.bias", 3 * d), Rows.of(qkv), 3 * d, d)
@@ -566,9 +574,10 @@ class FluxTransformer2DModel(torch.nn.Module):
             ops.gemm(Rows.of(nrm), self.W(f"{p}.proj_mlp.weight"), self.W(f"{p}.proj_mlp.bias"),
                      Rows(cat2[0, d:], M, 5 * d), 4 * d, d, EPI_BIAS_GELU,
                      aux=save["hid_pre"] if save is not None else (keep["hid_pre"] if ff_kept else None))
-        ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
-                         w.Q, w.K, None if vt_direct else w.Vt, B, H, S, w.Sp, S, 0, q_scale=self.q_scale(),
-                         **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
+        if not nograd:
+            ops.qk_norm_rope(qkv, self.W32(f"{p}.attn.norm_q.weight"), self.W32(f"{p}.attn.norm_k.weight"), cos, sin,
+                             w.Q, w.K, w.Vt, B, H, S, w.Sp, S, 0, q_scale=self.q_scale(),
+                             **({} if save is None else dict(V=save["V"], Qt=save["Qt"], Kt=save["Kt"])))
         if replay:                                   # attention output and proj_out result were kept by the forward
             if not ff_kept:
                 w.cat[:, :, :d].copy_(keep["O"])     # (the wgrad of proj_out then reads [O | mlp] as one [M, 5d] operand)

@@ -47,6 +47,8 @@ GEMM_PROFILE = None
 # MGX_LINEAR_VT=0: the value projection always leaves row-major and mgx_qk_norm_rope_fwd transposes it (the training passes
 # do that anyway: their backward needs V row-major as well)
 LINEAR_VT = os.environ.get("MGX_LINEAR_VT", "1") != "0"
+# MGX_LINEAR_QKNORM=0: the q | k projection always writes its [tokens, 2d] output and mgx_qk_norm_rope_fwd_qs makes Q, K of it
+LINEAR_QKNORM = os.environ.get("MGX_LINEAR_QKNORM", "1") != "0"
 
 
 def linear_t(X, W, bias, Ct, tokens, F, K, ld_ct, tok_rpb, ct_bstride):
@@ -185,6 +187,25 @@ def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S,
     check(lib().mgx_qk_norm_rope_bwd_qs(ptr(qkv), qkv.shape[-1], ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dQ), ptr(dK),
                                         ptr(dV), dqkv.data_ptr(), qkv.shape[-1] if ld_dqkv is None else ld_dqkv, ptr(gwq),
                                         ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0, float(q_scale), stream()))
+
+
+def linear_qk_norm_rope(X, Wqk, bias, wq, wk, cos, sin, Q, K, B, H, S, rows_per_batch, s0, Kdim, q_scale=1.0):
+    """Q, K [B, H, S, 128] <- qk_norm_rope(X @ Wqk^T + bias) in ONE launch (`mgx_linear_qk_norm_rope`: the norm / RoPE / head
+    split run in the GEMM's epilogue).  X plain [B * rows_per_batch, Kdim], Wqk [2 * H * 128, Kdim].  False -- nothing launched --
+    when the persistent kernel cannot take the problem: the caller keeps `gemm` + `qk_norm_rope`."""
+    prof = GEMM_PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().mgx_linear_qk_norm_rope(ptr(X), ptr(Wqk), ptr(bias), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K), B, H, S,
+                                       rows_per_batch, s0, Kdim, Kdim, Kdim, float(q_scale), stream())
+    if rc == 1:
+        return False
+    check(rc)
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * B * rows_per_batch * 2 * H * 128 * Kdim, (B * rows_per_batch, 2 * H * 128, Kdim, 5)))
+    return True
 
 
 def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):

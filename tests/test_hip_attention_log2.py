@@ -254,11 +254,12 @@ def test_model_with_and_without_prescaled_q_agree_with_the_oracle(monkeypatch):
     assert torch.nn.functional.cosine_similarity(res[0][1], res[1][1], dim=0).item() > 0.9995
 
 
-def test_forward_with_v_transposed_by_the_projection_equals_the_transposing_pass(monkeypatch):
-    """The no-grad forward (rollout) with V^T written by mgx_linear_bf16_t + q | k-only norm pass against the same forward with
-    the fused q | k | v projection and mgx_qk_norm_rope_fwd's transposing pass (MGX_LINEAR_VT=0), at a size where the persistent
-    kernel takes the value projection (d = 512 would not: FLUX width, one double + one single block, 2 x (256 + 1024) tokens),
-    stream-K off: every output element is the same K-loop in the same order, so the outputs are equal BIT FOR BIT."""
+def test_forward_with_fused_projections_equals_the_norm_pass(monkeypatch):
+    """The no-grad forward (rollout) three ways: (a) V^T written by mgx_linear_bf16_t and QK-norm / RoPE in the q | k projection's
+    epilogue (mgx_linear_qk_norm_rope), (b) V^T direct + q | k-only norm pass (MGX_LINEAR_QKNORM=0), (c) the fused q | k | v
+    projection + mgx_qk_norm_rope_fwd's transposing pass (MGX_LINEAR_VT=0), at a size where the persistent kernel takes the
+    projections (FLUX width, one double + one single block, 8 x (256 + 1024) tokens), stream-K off: every output element is the
+    same K-loop and the same norm arithmetic in the same order, so the outputs are equal BIT FOR BIT."""
     from mixgrpo_amd import ops
     from mixgrpo_amd.flux import FluxConfig, FluxTransformer2DModel
     cfg = dict(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=24, joint_attention_dim=64,
@@ -281,15 +282,18 @@ def test_forward_with_v_transposed_by_the_projection_equals_the_transposing_pass
     t = torch.full((B,), 0.7).cuda()
     gd = torch.tensor([3.5]).bfloat16().cuda()
     monkeypatch.setattr(ops, "GEMM_STREAM_K", False)
-    calls = []
-    real = ops.linear_t
-    monkeypatch.setattr(ops, "linear_t", lambda *a, **k: (calls.append(real(*a, **k)) or calls[-1]))
+    calls = {"vt": [], "qk": []}
+    real_t, real_qk = ops.linear_t, ops.linear_qk_norm_rope
+    monkeypatch.setattr(ops, "linear_t", lambda *a, **k: (calls["vt"].append(real_t(*a, **k)) or calls["vt"][-1]))
+    monkeypatch.setattr(ops, "linear_qk_norm_rope", lambda *a, **k: (calls["qk"].append(real_qk(*a, **k)) or calls["qk"][-1]))
     outs = []
-    for on in (True, False):
-        monkeypatch.setattr(ops, "LINEAR_VT", on)
+    for vt, qk in ((True, True), (True, False), (False, False)):
+        monkeypatch.setattr(ops, "LINEAR_VT", vt)
+        monkeypatch.setattr(ops, "LINEAR_QKNORM", qk)
         with torch.no_grad():
             outs.append(m._forward_nograd(x, ehs, t, gd, torch.zeros(L, 3).cuda(), pooled, ids).clone())
-    # text stream: 8 x 256 tokens = 12 x 8 = 96 tiles, declined (plain path inside the same forward); image stream and the
-    # single block's joint sequence: taken
-    assert calls == [False, True, True]
-    assert torch.equal(outs[0], outs[1])
+    # text stream: 8 x 256 tokens = 12 x 8 = 96 tiles of V^T, declined (plain path inside the same forward); image stream and the
+    # single block's joint sequence: taken, both times; the fused q | k epilogue: taken where it was tried
+    assert calls["vt"] == [False, True, True] * 2 and calls["qk"] == [True, True]
+    assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])

@@ -485,3 +485,57 @@ def test_linear_t_declines_what_the_persistent_kernel_cannot_take():
     Ct = torch.full((8, 3072, 1024), 7.0, dtype=torch.bfloat16, device="cuda")
     assert not ops.linear_t(X, W, None, Ct, 8000, 3072, 256, 1024, 1000, 3072 * 1024)        # 1000 % 64 != 0
     assert (Ct == 7.0).all()
+
+
+@pytest.mark.parametrize("B,rows,H,K,s0,S", [(8, 512, 24, 1024, 0, 4608), (4, 2176, 4, 512, 128, 2432), (6, 1280, 6, 256, 0, 1280),
+                                             (1, 4736, 8, 320, 64, 4800)])
+@pytest.mark.parametrize("q_scale,paired", [(1.0, False), (1.4426950408889634 / 128 ** 0.5, False), (1.4426950408889634 / 128 ** 0.5, True)])
+def test_linear_qk_norm_rope_equals_projection_then_norm_pass(B, rows, H, K, s0, S, q_scale, paired):
+    """mgx_linear_qk_norm_rope (RMSNorm + RoPE + head split in the q | k projection's epilogue: sums of squares crossing two
+    waves through LDS, the K-loop's early / late barrier protocol kept) against mgx_gemm_bf16 + mgx_qk_norm_rope_fwd_qs on the
+    same operands: the epilogue restates that kernel's arithmetic in its summation order, so Q and K are equal BIT FOR BIT;
+    positions outside s0 .. s0 + rows stay untouched.  (4736 rows: the last tile row is half outside the matrix.)"""
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.ops import Rows
+    g = torch.Generator().manual_seed(B * 7 + rows + H + K)
+    d, tokens = H * 128, B * rows
+    X = (torch.randn(tokens, K, generator=g) * 0.7).bfloat16().cuda()
+    W = (torch.randn(3 * d, K, generator=g) * 0.06).bfloat16().cuda()
+    bias = (torch.randn(3 * d, generator=g) * 0.3).bfloat16().cuda()
+    wq = (1 + 0.2 * torch.randn(128, generator=g)).cuda()
+    wk = (1 + 0.2 * torch.randn(128, generator=g)).cuda()
+    ang = torch.rand(S, 64, generator=g) * 6.28
+    cos = torch.cos(ang).repeat_interleave(2, dim=1).contiguous().cuda()
+    sin = torch.sin(ang).repeat_interleave(2, dim=1)
+    if not paired:                                   # general tables: the two entries of a pair differ
+        sin = sin * (1 + 0.01 * torch.randn(S, 128, generator=g))
+    sin = sin.contiguous().cuda()
+    Sp = (S + 63) // 64 * 64
+    Q1 = torch.full((B, H, S, 128), 7.0, dtype=torch.bfloat16, device="cuda")
+    K1 = torch.full_like(Q1, 7.0)
+    assert ops.linear_qk_norm_rope(X, W[:2 * d], bias[:2 * d], wq, wk, cos, sin, Q1, K1, B, H, S, rows, s0, K, q_scale=q_scale)
+    qkv = torch.zeros(tokens, 3 * d, dtype=torch.bfloat16, device="cuda")
+    sk_default = ops.GEMM_STREAM_K
+    ops.GEMM_STREAM_K = False
+    try:
+        ops.gemm(Rows.of(X), W[:2 * d], bias[:2 * d], Rows(qkv, tokens, 3 * d), 2 * d, K)
+    finally:
+        ops.GEMM_STREAM_K = sk_default
+    Q0 = torch.full_like(Q1, 7.0)
+    K0 = torch.full_like(Q1, 7.0)
+    ops.qk_norm_rope(qkv, wq, wk, cos, sin, Q0, K0, None, B, H, S, Sp, rows, s0, q_scale=q_scale)
+    assert (Q0[:, :, s0:s0 + rows] != 7.0).any()
+    assert torch.equal(Q1, Q0) and torch.equal(K1, K0)
+
+
+def test_linear_qk_norm_rope_declines():
+    from mixgrpo_amd import ops
+    z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device="cuda")
+    f = lambda *s: torch.zeros(*s, device="cuda")
+    # 3 heads (d = 384, not a multiple of 256) / rows % 128 != 0 / too few tiles
+    assert not ops.linear_qk_norm_rope(z(8192, 256), z(768, 256), z(768), f(128), f(128), f(1024, 128), f(1024, 128), z(8, 3, 1024, 128),
+                                       z(8, 3, 1024, 128), 8, 3, 1024, 1024, 0, 256)
+    assert not ops.linear_qk_norm_rope(z(8000, 256), z(1024, 256), z(1024), f(128), f(128), f(1000, 128), f(1000, 128), z(8, 4, 1000, 128),
+                                       z(8, 4, 1000, 128), 8, 4, 1000, 1000, 0, 256)
+    assert not ops.linear_qk_norm_rope(z(1024, 256), z(1024, 256), z(1024), f(128), f(128), f(1024, 128), f(1024, 128), z(1, 4, 1024, 128),
+                                       z(1, 4, 1024, 128), 1, 4, 1024, 1024, 0, 256)
