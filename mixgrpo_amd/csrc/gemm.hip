@@ -513,10 +513,6 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
   constexpr int AHEAD = 1, NSLOT = AHEAD + 1;
   float4 cs[NSLOT][8];                                // [ring slot][cos f0, cos f0+4, cos f1, cos f1+4, sin ...]
   auto load_cs = [&](int slot, int j, uint32_t dep) {
-#ifdef MGX_DIAG_QKN_NOLOAD      // scratch/qkn_diag.py only: price of the cos / sin loads (wrong results)
-    for (int q_ = 0; q_ < 8; ++q_) cs[slot][q_] = make_float4(0.5f + dep, 0.25f, 0.5f, 0.25f);
-    return;
-#endif
     const long o = (long)(j * 16 + dep) * 128;
     cs[slot][0] = *reinterpret_cast<const float4*>(cbase + o + f0);
     cs[slot][1] = *reinterpret_cast<const float4*>(cbase + o + f0 + 4);
@@ -587,9 +583,7 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef MGX_DIAG_QKN_NOBAR      // scratch/qkn_diag.py only: price of the exchange barrier (wrong results)
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < MT; ++j) ssq[j] = ssq[j] + rd[fr + 16 * j];                     // bit 5: the other half of the head

@@ -1,7 +1,8 @@
 """Price list of the EPI_QKNORM epilogue (mgx_linear_qk_norm_rope) at the rollout's shape (36864 tokens, H 24, K 3072): the plain
-q | k projection (mgx_gemm_bf16, N = 6144) + norm pass against the fused launch, and timing-only builds of gemm.hip without the
-cos / sin loads (-DMGX_DIAG_QKN_NOLOAD) and without the exchange barrier (-DMGX_DIAG_QKN_NOBAR).  Builds its own libraries
-from csrc/gemm.hip + api.hip into scratch/ (never the product library)."""
+q | k projection (mgx_gemm_bf16, N = 6144) + norm pass against the fused launch, and a build under -fno-slp-vectorize.
+(The timing-only variants of profiles/r04_qknorm_epilogue_prices.log -- no cos / sin loads, no exchange barrier -- were
+`#ifdef MGX_DIAG_QKN_NOLOAD / _NOBAR` blocks in qknorm_epilogue; they are out of the product source again: to repeat them, stub
+`load_cs` with constants / drop the s_barrier in a scratch copy.)  Builds its own libraries into scratch/."""
 import ctypes as C, json, os, subprocess, sys, torch
 sys.path.insert(0, ".")
 from mixgrpo_amd import _lib, ops
@@ -15,7 +16,7 @@ def build(tag, flags):
     res, args = _lib.SIGNATURES["mgx_linear_qk_norm_rope"]
     lib.mgx_linear_qk_norm_rope.restype, lib.mgx_linear_qk_norm_rope.argtypes = res, args
     return lib
-variants = {"noload": build("noload", ["-DMGX_DIAG_QKN_NOLOAD"])}
+variants = {}
 noslp = build("noslp", ["-fno-slp-vectorize"])
 torch.manual_seed(0)
 B, rows, H, K, S = 8, 4608, 24, 3072, 4608
