@@ -164,11 +164,15 @@ int mgx_gemm_bf16_sk(const uint16_t* A, const uint16_t* W, const uint16_t* bias,
  * -> Q, K [B, H, S, 128] at sequence positions s0 .. s0 + rows_per_batch - 1, Q times q_scale.  The [tokens, 2 H 128]
  * projection output is neither written nor re-read.  Same bits as mgx_gemm_bf16 followed by mgx_qk_norm_rope_fwd_qs
  * (diffusers' to_q / to_k Linears + norm_q / norm_k + apply_rotary_emb; call sites fastvideo/utils/sampling_utils.py:68-82).
+ * cos_sin_pairs (optional): [S, 64, 2] fp32 = (cos[s][2i], sin[s][2i]) for tables whose two entries of a rotation pair are
+ * equal (diffusers' FluxPosEmbed repeat_interleaves them) -- the caller's promise; the epilogue then reads half the table
+ * bytes, which are what it costs (profiles/r04_qknorm_epilogue_prices.log).
  * Returns 1 -- nothing launched -- when the persistent kernel cannot take the problem (fewer than 128 output tiles of
  * 256 x 256, H odd, rows_per_batch % 128 != 0, alignments below 16 bytes, MGX_GEMM_QKNORM=0): keep the two-pass form. */
 int mgx_linear_qk_norm_rope(const uint16_t* X, const uint16_t* Wqk, const uint16_t* bias, const float* wq, const float* wk,
-                            const float* cos, const float* sin, uint16_t* Q, uint16_t* K, int B, int H, int S,
-                            int rows_per_batch, int s0, int Kdim, long ldx, long ldw, float q_scale, void* stream);
+                            const float* cos, const float* sin, const float* cos_sin_pairs /* optional, see above */,
+                            uint16_t* Q, uint16_t* K, int B, int H, int S, int rows_per_batch, int s0, int Kdim, long ldx,
+                            long ldw, float q_scale, void* stream);
 
 /* A Linear whose output leaves TRANSPOSED: Ct[b][f][t] = bf16(X[b * tok_rpb + t, :] . W[f, :] + bias[f]), ld_ct elements
  * between feature rows, ct_bstride between token batches -- the V^T [B, H, 128, Sp] operand of mgx_attn_fwd* straight from

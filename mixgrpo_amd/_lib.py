@@ -59,7 +59,7 @@ SIGNATURES = {
     "mgx_gemm_sk_workspace_elems": (_L, []),
     "mgx_gemm_bf16_sk": (_I, [_P] * 6 + [_L, _I, _I, _I] + [_L] * 8 + [_I, _F, _P, _L, _P]),
     "mgx_linear_bf16_t": (_I, [_P] * 4 + [_I] * 3 + [_L] * 5 + [_P, _L, _P]),
-    "mgx_linear_qk_norm_rope": (_I, [_P] * 9 + [_I] * 6 + [_L, _L, _F, _P]),
+    "mgx_linear_qk_norm_rope": (_I, [_P] * 10 + [_I] * 6 + [_L, _L, _F, _P]),
     "mgx_gemm_bf16_pair": (_I, ([_P] * 6 + [_I] + [_L] * 4) * 2 + [_I, _I] + [_L] * 5 + [_I, _F, _P, _L, _P]),
     "mgx_transpose_partial_elems": (_L, [_I, _I]),
     "mgx_transpose_bf16": (_I, [_P, _P, _P, _P, _F, _I, _I, _L, _L, _L, _L, _P]),

@@ -37,7 +37,9 @@ __device__ __forceinline__ long row_off(const RowMap& r, long m) {
 }
 
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2, EPI_F32_ACC = 3, EPI_BIAS_MULAUX = 4,
-           EPI_QKNORM = 5 /* internal (mgx_linear_qk_norm_rope): bias, per-head RMSNorm, RoPE, head split */ };
+           EPI_QKNORM = 5 /* internal (mgx_linear_qk_norm_rope): bias, per-head RMSNorm, RoPE, head split */,
+           EPI_QKNORM_P = 6 /* the same reading a (cos, sin)-per-pair table: a kernel of its own -- a run-time choice inside the
+                               epilogue sends its register arrays to scratch */ };
 
 struct GemmArgs {
   const bf16_raw* A;
@@ -88,6 +90,8 @@ struct GemmArgs {
   const float* qn_wk;
   const float* qn_cos;    // [S, 128] fp32
   const float* qn_sin;
+  const float* qn_cs2;    // EPI_QKNORM_P: [S, 64, 2] fp32 (cos, sin) per rotation pair, for tables whose two entries of a pair are
+                          // equal (FLUX's): half the epilogue's table bytes
   bf16_raw* qn_Q;         // [B, H, S, 128]
   bf16_raw* qn_K;
   int qn_H, qn_S, qn_s0, qn_dmodel;
@@ -481,6 +485,13 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 // it exactly once per tile, so the early / late halves of the K-loop stay one barrier apart.  `red`: the A stage the NEXT
 // K-tile DMA will fill; a wave's sums are written where its PARTNER's first DMA piece lands (bytes (wu ^ 1) * 1024 ..), so only
 // the reader itself can overwrite them, after it has read.
+// single-instruction fp32 ops the SLP vectoriser cannot pack (a plain -O3 build turns the pair form's adjacent multiplies into
+// v_pk_mul_f32 on register pairs and spills 200 bytes per lane around them: 1.217 ms against 1.123 ms without SLP)
+__device__ __forceinline__ float vmul1(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vsub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vadd1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <bool PAIRED>
 __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int wid, int lane, long m0, long n0,
                                                 char* red) {
 #pragma clang fp contract(off)
@@ -510,10 +521,18 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
   // (profiles/r04_qknorm_epilogue_prices.log).  A (cos, sin)-per-pair table (FLUX's tables repeat every pair's entry: half the
   // bytes) two rows ahead was built and measured: 1.217 ms as hipcc compiles it (200 bytes of spills per lane), 1.123 ms under
   // -fno-slp-vectorize, which costs this general form 0.07 ms -- not kept.
-  constexpr int AHEAD = 1, NSLOT = AHEAD + 1;
-  float4 cs[NSLOT][8];                                // [ring slot][cos f0, cos f0+4, cos f1, cos f1+4, sin ...]
+  constexpr int AHEAD = PAIRED ? 2 : 1, NSLOT = AHEAD + 1;      // the pair form's rows are half the registers: two rows ahead
+  float4 cs[NSLOT][PAIRED ? 4 : 8];                   // [ring slot][cos f0, cos f0+4, cos f1, cos f1+4, sin ...] / [(cos, sin) x 4 pairs] x 4
+  const float* pbase = g.qn_cs2 + (long)(g.qn_s0 + t0 + fr) * 128 + hb;      // (64 pairs x 2 floats = 128 floats per row as well)
   auto load_cs = [&](int slot, int j, uint32_t dep) {
     const long o = (long)(j * 16 + dep) * 128;
+    if constexpr (PAIRED) {
+      cs[slot][0] = *reinterpret_cast<const float4*>(pbase + o + f0);
+      cs[slot][1] = *reinterpret_cast<const float4*>(pbase + o + f0 + 4);
+      cs[slot][2] = *reinterpret_cast<const float4*>(pbase + o + f1);
+      cs[slot][3] = *reinterpret_cast<const float4*>(pbase + o + f1 + 4);
+      return;
+    }
     cs[slot][0] = *reinterpret_cast<const float4*>(cbase + o + f0);
     cs[slot][1] = *reinterpret_cast<const float4*>(cbase + o + f0 + 4);
     cs[slot][2] = *reinterpret_cast<const float4*>(cbase + o + f1);
@@ -567,8 +586,10 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
     unpack8(y[j][0], x);
     unpack8(y[j][1], x + 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
-    float sacc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));     // pair-index bits 0, 1, then 4
+    for (int i = 0; i < 8; ++i)
+      p[i] = PAIRED ? vadd1(vmul1(x[2 * i], x[2 * i]), vmul1(x[2 * i + 1], x[2 * i + 1])) : x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+    float sacc = PAIRED ? vadd1(vadd1(vadd1(p[0], p[1]), vadd1(p[2], p[3])), vadd1(vadd1(p[4], p[5]), vadd1(p[6], p[7])))
+                        : ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));     // pair-index bits 0, 1, then 4
     sacc += __shfl_xor(sacc, 16, 64);                                                   // bit 2
     sacc += __shfl_xor(sacc, 32, 64);                                                   // bit 3
     ssq[j] = sacc;
@@ -602,16 +623,31 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
     float x[16], o[16];
     unpack8(y[j][0], x);
     unpack8(y[j][1], x + 8);
+    if constexpr (PAIRED) {
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const float4 cv = cs[slot][q4], sv = cs[slot][4 + q4];
-      const float c[4] = {cv.x, cv.y, cv.z, cv.w}, sn[4] = {sv.x, sv.y, sv.z, sv.w};
+      for (int q4 = 0; q4 < 4; ++q4) {                 // (cos, sin) of the lane's pairs 2 q4 and 2 q4 + 1
+        const float4 v = cs[slot][q4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * q4 + h;
-        const float y0 = x[2 * i] * r * wv[2 * i], y1 = x[2 * i + 1] * r * wv[2 * i + 1];
-        o[2 * i] = y0 * c[2 * h] - y1 * sn[2 * h];
-        o[2 * i + 1] = y1 * c[2 * h + 1] + y0 * sn[2 * h + 1];
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * q4 + h;
+          const float cv = h ? v.z : v.x, sv = h ? v.w : v.y;
+          const float y0 = vmul1(vmul1(x[2 * i], r), wv[2 * i]), y1 = vmul1(vmul1(x[2 * i + 1], r), wv[2 * i + 1]);
+          o[2 * i] = vsub1(vmul1(y0, cv), vmul1(y1, sv));
+          o[2 * i + 1] = vadd1(vmul1(y1, cv), vmul1(y0, sv));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 cv = cs[slot][q4], sv = cs[slot][4 + q4];
+        const float c[4] = {cv.x, cv.y, cv.z, cv.w}, sn[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * q4 + h;
+          const float y0 = x[2 * i] * r * wv[2 * i], y1 = x[2 * i + 1] * r * wv[2 * i + 1];
+          o[2 * i] = y0 * c[2 * h] - y1 * sn[2 * h];
+          o[2 * i + 1] = y1 * c[2 * h + 1] + y0 * sn[2 * h + 1];
+        }
       }
     }
     y[j][0] = pack8(o);
@@ -627,8 +663,8 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
 template <int EPI>
 __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int wid, int lane, long m0,
                                                  long n0, char* red = nullptr) {
-  if constexpr (EPI == EPI_QKNORM) {
-    qknorm_epilogue(g, acc, wid, lane, m0, n0, red);
+  if constexpr (EPI == EPI_QKNORM || EPI == EPI_QKNORM_P) {
+    qknorm_epilogue<EPI == EPI_QKNORM_P>(g, acc, wid, lane, m0, n0, red);
     return;
   }
   constexpr int MT = 8;
@@ -965,7 +1001,7 @@ __global__ void __launch_bounds__(64) gemm_sk_fixup_kernel(GemmArgs g, int nw) {
   long m0 = (long)(b0 * band + in_band % rows_in_band) * 256;
   const long n0 = (long)(in_band / rows_in_band) * 256;
   const GemmArgs gl = seg_args<PAIR>(g, m0);
-  if constexpr (EPI != EPI_QKNORM) persist_epilogue<EPI>(gl, acc, wid, lane, m0, n0);   // (QKNORM launches never split: launch())
+  if constexpr (EPI != EPI_QKNORM && EPI != EPI_QKNORM_P) persist_epilogue<EPI>(gl, acc, wid, lane, m0, n0);   // (QKNORM launches never split: launch())
 }
 
 // ------------------------------------------------------------------------------------------ persistent ping-pong kernel
@@ -1253,7 +1289,7 @@ int launch(const GemmArgs& g_in, hipStream_t st) {
     attr_set = true;
   }
   const bool pair = !CONV && g.m_split != 0;
-  if (EPI == EPI_QKNORM) g.sk_ws = nullptr;          // its epilogue needs the whole workgroup: no split tiles
+  if (EPI == EPI_QKNORM || EPI == EPI_QKNORM_P) g.sk_ws = nullptr;     // its epilogue needs the whole workgroup: no split tiles
   if (persistent_ok(g)) {
     int grid = 256;                       // one workgroup per CU (multiple of 8: XCD ranges)
     // stream-K tail (caller gave a workspace): allowed when it shortens the launch.  A tile's K-loop takes T ~ K * 0.0247 us
@@ -1479,10 +1515,11 @@ extern "C" int mgx_linear_bf16_t(const uint16_t* X, const uint16_t* W, const uin
 // followed by mgx_qk_norm_rope_fwd_qs.  Returns 1 -- nothing launched -- when the persistent kernel cannot take the problem
 // (fewer than 128 tiles of 256 x 256, H odd, rows_per_batch % 128 != 0, alignments): the caller keeps the two-pass form.
 extern "C" int mgx_linear_qk_norm_rope(const uint16_t* X, const uint16_t* Wqk, const uint16_t* bias, const float* wq,
-                                       const float* wk, const float* cos, const float* sin, uint16_t* Q, uint16_t* K, int B,
-                                       int H, int S, int rows_per_batch, int s0, int Kdim, long ldx, long ldw, float q_scale,
-                                       void* stream) {
+                                       const float* wk, const float* cos, const float* sin, const float* cos_sin_pairs,
+                                       uint16_t* Q, uint16_t* K, int B, int H, int S, int rows_per_batch, int s0, int Kdim,
+                                       long ldx, long ldw, float q_scale, void* stream) {
   MGX_REQUIRE(X && Wqk && wq && wk && cos && sin && Q && K, "null argument");
+  MGX_REQUIRE(!cos_sin_pairs || (uintptr_t)cos_sin_pairs % 16 == 0, "pair table must be 16-byte aligned");
   MGX_REQUIRE(B > 0 && H > 0 && rows_per_batch > 0 && s0 >= 0 && s0 + rows_per_batch <= S && Kdim > 0 && q_scale > 0.f, "bad sizes");
   static const int off = getenv("MGX_GEMM_QKNORM") ? atoi(getenv("MGX_GEMM_QKNORM")) == 0 : 0;
   const long tokens = (long)B * rows_per_batch;
@@ -1501,10 +1538,10 @@ extern "C" int mgx_linear_qk_norm_rope(const uint16_t* X, const uint16_t* Wqk, c
   g.conv_shift = -1;
   g.rowwise_ok = 1;
   g.span32 = (tokens * ldx) * 2 < (1L << 32) && ((long)g.N * ldw) * 2 < (1L << 32);
-  g.qn_wq = wq; g.qn_wk = wk; g.qn_cos = cos; g.qn_sin = sin; g.qn_Q = Q; g.qn_K = K;
+  g.qn_wq = wq; g.qn_wk = wk; g.qn_cos = cos; g.qn_sin = sin; g.qn_cs2 = cos_sin_pairs; g.qn_Q = Q; g.qn_K = K;
   g.qn_H = H; g.qn_S = S; g.qn_s0 = s0; g.qn_dmodel = dmodel; g.qn_qscale = q_scale;
   if (!persistent_ok(g)) return 1;
-  return launch<EPI_QKNORM>(g, (hipStream_t)stream);
+  return cos_sin_pairs ? launch<EPI_QKNORM_P>(g, (hipStream_t)stream) : launch<EPI_QKNORM>(g, (hipStream_t)stream);
 }
 
 extern "C" int mgx_gemm_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* bias, void* C, const uint16_t* gate,

@@ -381,7 +381,8 @@ class FluxTransformer2DModel(torch.nn.Module):
         B = tokens // rows
         vt = ops.LINEAR_VT and ops.linear_t(nrm, Wf[2 * d:], bf[2 * d:], w.Vt.view(-1)[s0:], tokens, d, d, w.Sp, rows, d * w.Sp)
         if vt and ops.LINEAR_QKNORM and H * 128 == d and ops.linear_qk_norm_rope(
-                nrm, Wf[:2 * d], bf[:2 * d], wq, wk, cos, sin, w.Q, w.K, B, H, w.S, rows, s0, d, q_scale=self.q_scale()):
+                nrm, Wf[:2 * d], bf[:2 * d], wq, wk, cos, sin, w.Q, w.K, B, H, w.S, rows, s0, d, q_scale=self.q_scale(),
+                pairs=self._rope_pairs(cos, sin)):
             return
         if vt:
             ops.gemm(Rows.of(nrm), Wf[:2 * d], bf[:2 * d], Rows(qkv, tokens, 3 * d), 2 * d, d)
@@ -407,6 +408,17 @@ class FluxTransformer2DModel(torch.nn.Module):
         cos, sin = rope_tables(ids, self.cfg.axes_dims_rope)
         self._rope_cache["k"] = (key, cos, sin, txt_ids, img_ids)   # keep the id tensors alive with the key
         return cos, sin
+
+    def _rope_pairs(self, cos, sin):
+        """[S, 64, 2] (cos, sin) per rotation pair for `mgx_linear_qk_norm_rope` when the tables repeat every pair's entry
+        (FluxPosEmbed's do), else None; cached with the tables (MGX_ROPE_PAIR_TABLE=0: never)."""
+        if not ops.ROPE_PAIR_TABLE:
+            return None
+        hit = self._rope_cache.get("pairs")
+        if hit is None or hit[0] is not cos:
+            hit = (cos, ops.rope_pair_table(cos, sin))
+            self._rope_cache["pairs"] = hit
+        return hit[1]
 
     def _temb(self, B, timestep, guidance, pooled, keep=None):
         """temb = t_emb + g_emb + text_emb (bf16 after every op), st = silu(temb)."""

@@ -49,6 +49,7 @@ GEMM_PROFILE = None
 LINEAR_VT = os.environ.get("MGX_LINEAR_VT", "1") != "0"
 # MGX_LINEAR_QKNORM=0: the q | k projection always writes its [tokens, 2d] output and mgx_qk_norm_rope_fwd_qs makes Q, K of it
 LINEAR_QKNORM = os.environ.get("MGX_LINEAR_QKNORM", "1") != "0"
+ROPE_PAIR_TABLE = os.environ.get("MGX_ROPE_PAIR_TABLE", "1") != "0"   # that epilogue reads (cos, sin) per pair when the tables allow
 
 
 def linear_t(X, W, bias, Ct, tokens, F, K, ld_ct, tok_rpb, ct_bstride):
@@ -189,16 +190,17 @@ def qk_norm_rope_bwd(qkv, wq, wk, cos, sin, dQ, dK, dV, dqkv, gwq, gwk, B, H, S,
                                         ptr(gwk), ptr(ws), B, H, S, Sp, rows_per_batch, s0, float(q_scale), stream()))
 
 
-def linear_qk_norm_rope(X, Wqk, bias, wq, wk, cos, sin, Q, K, B, H, S, rows_per_batch, s0, Kdim, q_scale=1.0):
+def linear_qk_norm_rope(X, Wqk, bias, wq, wk, cos, sin, Q, K, B, H, S, rows_per_batch, s0, Kdim, q_scale=1.0, pairs=None):
     """Q, K [B, H, S, 128] <- qk_norm_rope(X @ Wqk^T + bias) in ONE launch (`mgx_linear_qk_norm_rope`: the norm / RoPE / head
     split run in the GEMM's epilogue).  X plain [B * rows_per_batch, Kdim], Wqk [2 * H * 128, Kdim].  False -- nothing launched --
-    when the persistent kernel cannot take the problem: the caller keeps `gemm` + `qk_norm_rope`."""
+    when the persistent kernel cannot take the problem: the caller keeps `gemm` + `qk_norm_rope`.  `pairs`: [S, 64, 2] (cos, sin)
+    per rotation pair when both entries of every pair of `cos` / `sin` are equal (`rope_pair_table`): half the table bytes."""
     prof = GEMM_PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().mgx_linear_qk_norm_rope(ptr(X), ptr(Wqk), ptr(bias), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(Q), ptr(K), B, H, S,
-                                       rows_per_batch, s0, Kdim, Kdim, Kdim, float(q_scale), stream())
+    rc = lib().mgx_linear_qk_norm_rope(ptr(X), ptr(Wqk), ptr(bias), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(pairs), ptr(Q), ptr(K),
+                                       B, H, S, rows_per_batch, s0, Kdim, Kdim, Kdim, float(q_scale), stream())
     if rc == 1:
         return False
     check(rc)
@@ -206,6 +208,13 @@ def linear_qk_norm_rope(X, Wqk, bias, wq, wk, cos, sin, Q, K, B, H, S, rows_per_
         e1.record()
         GEMM_PROFILE.append((e0, e1, 2.0 * B * rows_per_batch * 2 * H * 128 * Kdim, (B * rows_per_batch, 2 * H * 128, Kdim, 5)))
     return True
+
+
+def rope_pair_table(cos, sin):
+    """[S, 64, 2] (cos, sin) per rotation pair if the two entries of every pair are equal in both tables, else None."""
+    if not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+        return None
+    return torch.stack([cos[:, 0::2], sin[:, 0::2]], dim=-1).contiguous()
 
 
 def attn_fwd(Q, K, Vt, O_ptr_tensor, lse, B, H, S, Sp, ldo, o_bstride, scale):

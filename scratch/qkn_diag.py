@@ -26,6 +26,7 @@ W = (torch.randn(2 * d, K, device="cuda") * 0.02).bfloat16()
 bias = torch.zeros(2 * d, device="cuda", dtype=torch.bfloat16)
 wq = torch.ones(128, device="cuda"); wk = torch.ones(128, device="cuda")
 cos = torch.rand(S, 64, device="cuda").repeat_interleave(2, dim=1).contiguous(); sin = torch.rand(S, 64, device="cuda").repeat_interleave(2, dim=1).contiguous()
+pairs = ops.rope_pair_table(cos, sin)
 
 Q = torch.empty(B, H, S, 128, device="cuda", dtype=torch.bfloat16); Kt = torch.empty_like(Q)
 qkv = torch.empty(tokens, 3 * d, device="cuda", dtype=torch.bfloat16)
@@ -41,11 +42,12 @@ def t(fn, n=10):
 ops.GEMM_STREAM_K = False
 cases = {"plain_gemm_N6144": lambda: ops.gemm(Rows.of(X), W, bias, Rows(qkv, tokens, 3 * d), 2 * d, K),
          "norm_pass_qk_only": lambda: ops.qk_norm_rope(qkv, wq, wk, cos, sin, Q, Kt, None, B, H, S, S, rows, 0),
-         "fused_general_tables": lambda: ops.linear_qk_norm_rope(X, W, bias, wq, wk, cos, sin, Q, Kt, B, H, S, rows, 0, K)}
+         "fused_general_tables": lambda: ops.linear_qk_norm_rope(X, W, bias, wq, wk, cos, sin, Q, Kt, B, H, S, rows, 0, K),
+         "fused_pair_table": lambda: ops.linear_qk_norm_rope(X, W, bias, wq, wk, cos, sin, Q, Kt, B, H, S, rows, 0, K, pairs=pairs)}
 for name, lib in variants.items():
-    cases["fused_" + name] = (lambda lib=lib: lib.mgx_linear_qk_norm_rope(p(X), p(W), p(bias), p(wq), p(wk), p(cos), p(sin), p(Q), p(Kt),
+    cases["fused_" + name] = (lambda lib=lib: lib.mgx_linear_qk_norm_rope(p(X), p(W), p(bias), p(wq), p(wk), p(cos), p(sin), None, p(Q), p(Kt),
                                                                           B, H, S, rows, 0, K, K, K, 1.0, st))
-cases["fused_general_noslp"] = lambda: noslp.mgx_linear_qk_norm_rope(p(X), p(W), p(bias), p(wq), p(wk), p(cos), p(sin), p(Q), p(Kt), B, H, S, rows, 0, K, K, K, 1.0, st)
+cases["fused_general_noslp"] = lambda: noslp.mgx_linear_qk_norm_rope(p(X), p(W), p(bias), p(wq), p(wk), p(cos), p(sin), None, p(Q), p(Kt), B, H, S, rows, 0, K, K, K, 1.0, st)
 res = {k: [] for k in cases}
 for rep in range(3):
     for k, fn in cases.items():

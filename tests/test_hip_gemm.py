@@ -510,10 +510,13 @@ def test_linear_qk_norm_rope_equals_projection_then_norm_pass(B, rows, H, K, s0,
     if not paired:                                   # general tables: the two entries of a pair differ
         sin = sin * (1 + 0.01 * torch.randn(S, 128, generator=g))
     sin = sin.contiguous().cuda()
+    pairs = ops.rope_pair_table(cos, sin)
+    assert (pairs is not None) == paired
     Sp = (S + 63) // 64 * 64
     Q1 = torch.full((B, H, S, 128), 7.0, dtype=torch.bfloat16, device="cuda")
     K1 = torch.full_like(Q1, 7.0)
-    assert ops.linear_qk_norm_rope(X, W[:2 * d], bias[:2 * d], wq, wk, cos, sin, Q1, K1, B, H, S, rows, s0, K, q_scale=q_scale)
+    assert ops.linear_qk_norm_rope(X, W[:2 * d], bias[:2 * d], wq, wk, cos, sin, Q1, K1, B, H, S, rows, s0, K, q_scale=q_scale,
+                                   pairs=pairs)
     qkv = torch.zeros(tokens, 3 * d, dtype=torch.bfloat16, device="cuda")
     sk_default = ops.GEMM_STREAM_K
     ops.GEMM_STREAM_K = False
