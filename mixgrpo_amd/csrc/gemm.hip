@@ -141,6 +141,10 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// single-instruction fp32 ops the SLP vectoriser cannot pack into v_pk_*_f32 (MI355X_MICROARCH.md: packed fp32 beside MFMAs is an
+// anti-lever; the two waves of a SIMD run their epilogues beside each other's MFMA sections)
+__device__ __forceinline__ float vfma1(float sa /* wave-uniform */, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(sa), "v"(b), "v"(c)); return r; }
+
 // Epilogue of the 128x128 kernel: lane holds, for m-tile j and n-tile i, 4 consecutive features of one token.
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NTL][MT], int lane, long m0, long n0, int wm,
@@ -706,9 +710,11 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
         for (int t = 0; t < 4; ++t) {
           const f32x4 a = acc[t][jb + jj];
           float4 o = make_float4(a[0], a[1], a[2], a[3]);
-          if (rmw) {
-            o.x += g.beta * old[jj][t].x; o.y += g.beta * old[jj][t].y;
-            o.z += g.beta * old[jj][t].z; o.w += g.beta * old[jj][t].w;
+          if (rmw) {                                  // one v_fma_f32 each: as v_pk_fma_f32 (what -O3's SLP pass makes of the four) this
+            o.x = vfma1(g.beta, old[jj][t].x, o.x);   // epilogue ran 2 % slower beside the partner wave's MFMAs (profiles/r04_gemm_noslp_ab.log)
+            o.y = vfma1(g.beta, old[jj][t].y, o.y);
+            o.z = vfma1(g.beta, old[jj][t].z, o.z);
+            o.w = vfma1(g.beta, old[jj][t].w, o.w);
           }
           if (rok[jj] && nok[t]) *reinterpret_cast<float4*>(Cb + off[jj] + ncol[t]) = o;
         }
