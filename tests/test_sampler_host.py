@@ -50,3 +50,26 @@ def test_schedule_helpers_pinned_to_the_reference():
         sig, ts = SF.flow_match_sigmas(T, case["mu"], sigmas=grid)              # the product takes the same grid ...
         sig2, _ = SF.flow_match_sigmas(T, case["mu"])                           # ... and builds the same one itself
         assert torch.equal(sig, sig2) and sig.shape == (T + 1,) and sig[-1] == 0 and torch.equal(ts, sig[:-1] * 1000.0)
+
+
+def test_rope_pair_table_only_for_tables_that_repeat_each_pair():
+    """`ops.rope_pair_table` (host logic behind mgx_linear_qk_norm_rope's optional (cos, sin)-per-pair table): built from the
+    model's own rope tables (`flux.rope_tables`, FluxPosEmbed's repeat_interleave layout: both entries of a rotation pair
+    equal), refused for tables where they differ."""
+    import torch
+    from mixgrpo_amd import ops
+    from mixgrpo_amd.flux import rope_tables
+    ids = torch.zeros(40, 3)
+    ids[:, 1] = torch.arange(40) // 8
+    ids[:, 2] = torch.arange(40) % 8
+    cos, sin = rope_tables(ids, (16, 56, 56))
+    assert cos.shape == (40, 128) and cos.dtype == torch.float32
+    pairs = ops.rope_pair_table(cos, sin)
+    assert pairs is not None and pairs.shape == (40, 64, 2) and pairs.is_contiguous()
+    assert torch.equal(pairs[:, :, 0], cos[:, 0::2]) and torch.equal(pairs[:, :, 1], sin[:, 1::2])
+    sin2 = sin.clone()
+    sin2[3, 5] += 1e-3
+    assert ops.rope_pair_table(cos, sin2) is None
+    cos2 = cos.clone()
+    cos2[0, 0] -= 1e-3
+    assert ops.rope_pair_table(cos2, sin) is None
