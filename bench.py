@@ -343,6 +343,9 @@ def main():
                            "seq_len": n_img + L, "parallelism": f"dp{world}", "train_microbatch": a.train_microbatch,
                            "train_ff_blocks_kept": (model.ff_blocks_kept() if hasattr(model, "ff_blocks_kept") else 0),
                            "train_qkv_blocks_kept": (model.qkv_blocks_kept() if hasattr(model, "qkv_blocks_kept") else 0),
+                           # the no-grad forward's attention plumbing (mixgrpo_amd/ops.py switches; all on by default)
+                           "rollout_attention": {"q_prescaled": bool(ops.Q_PRESCALE), "vt_from_projection": bool(ops.LINEAR_VT),
+                                                 "qk_norm_in_epilogue": bool(ops.LINEAR_QKNORM), "rope_pair_table": bool(ops.ROPE_PAIR_TABLE)},
                            "skip_dead_backward": bool(a.skip_dead_backward),
                            "algorithmic_pflop_per_image": round(flop_img / 1e15, 3),
                            "executed_pflop_per_image": round(flop_img_executed / 1e15, 3)},
