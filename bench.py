@@ -75,8 +75,10 @@ def flops_per_forward(cfg, n_img, n_txt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: two untimed steps first -- the SECOND train step of a process allocates the keep buffers' growth (114 device
+    # allocations, 0.3-1.2 s on a cold box: `allocator_in_timed_region`), so one warm-up step would put it in the timed region
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="flux1dev_1024_T25_W4_G8", choices=list(WORKLOADS))
     ap.add_argument("--train-microbatch", type=int, default=4,
                     help="replayed (sample, step) pairs per forward/backward.  4 -> micro-batches of 4+4+4 (and 4+4 for the "
