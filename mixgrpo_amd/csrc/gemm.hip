@@ -520,11 +520,12 @@ __device__ __forceinline__ void qknorm_epilogue(const GemmArgs& g, f32x4 (&acc)[
   // cos / sin rows of the lane: sequence position s0 + t0 + fr + 16 j, features hb + f0 .. +7 and hb + f1 .. +7
   const float* cbase = g.qn_cos + (long)(g.qn_s0 + t0 + fr) * 128 + hb;
   const float* sbase = g.qn_sin + (long)(g.qn_s0 + t0 + fr) * 128 + hb;
-  // ring of table rows in flight, one row ahead of the arithmetic.  The epilogue's cost IS these loads -- 512 KiB per tile through
-  // the CU's L1: 1.164 ms fused, 1.037 ms without them, 1.020 ms the plain projection, 0.212 ms the norm pass it replaces
-  // (profiles/r04_qknorm_epilogue_prices.log).  A (cos, sin)-per-pair table (FLUX's tables repeat every pair's entry: half the
-  // bytes) two rows ahead was built and measured: 1.217 ms as hipcc compiles it (200 bytes of spills per lane), 1.123 ms under
-  // -fno-slp-vectorize, which costs this general form 0.07 ms -- not kept.
+  // ring of table rows in flight ahead of the arithmetic.  The epilogue's cost IS these loads -- with the general tables 512 KiB
+  // per tile through the CU's L1: 1.164 ms fused, 1.037 ms without them, 1.020 ms the plain projection, 0.212 ms the norm pass it
+  // replaces (profiles/r04_qknorm_epilogue_prices.log).  PAIRED (EPI_QKNORM_P): a (cos, sin)-per-pair table for tables that repeat
+  // every pair's entry (FLUX's) -- half the bytes, half the registers per row, so two rows ahead: 1.065 ms
+  // (r04_qknorm_epilogue_prices_pair_table.log), once its arithmetic is the one-instruction helpers above (as plain C++ the SLP pass
+  // packs it and the kernel spills 200 bytes per lane: 1.217 ms; three rows ahead spills again).
   constexpr int AHEAD = PAIRED ? 2 : 1, NSLOT = AHEAD + 1;      // the pair form's rows are half the registers: two rows ahead
   float4 cs[NSLOT][PAIRED ? 4 : 8];                   // [ring slot][cos f0, cos f0+4, cos f1, cos f1+4, sin ...] / [(cos, sin) x 4 pairs] x 4
   const float* pbase = g.qn_cs2 + (long)(g.qn_s0 + t0 + fr) * 128 + hb;      // (64 pairs x 2 floats = 128 floats per row as well)
